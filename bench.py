@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/sec, FastGRNN forward+backward, T=99 feat=32
+hidden=128, bs=4096 per GPU (BASELINE.json `metric`), fp32, synthetic MFCC frames.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL);
+batch shards data-parallel (weak scaling: 4096 utterances per GPU) and the parameter
+gradients are all-reduced in one flattened bucket per step.  Rank 0 prints ONE JSON line.
+A "step" = zero grads, forward over the whole [T,B,F] batch, backward with a dense
+grad_hs ~ N(0,1), and (N > 1) the gradient all-reduce; inputs are resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T, F, H, B_PER_GPU = 99, 32, 128, 4096
+# algorithmic work per utterance (dense, fp32)
+FLOPS_FWD = T * (2 * F * H + 2 * H * H)          # 4 055 040
+FLOPS_BWD = 2 * FLOPS_FWD                        # 8 110 080
+BYTES_FWD = 4 * T * (F + H)                      # 63 360: read x, write hs
+BYTES_BWD = 4 * T * (2 * H + 2 * F)              # 126 720: read grad_hs, hs, x; write d_x
+PEAK_F32_TFLOPS = 157.3                          # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_HBM_GBS = 8000.0                            # spec; ~6300 achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kws_amd import FastGRNNCUDA, fastgrnn_cuda
+    from kws_amd.dp import GradBucket
+
+    B = args.batch
+    torch.manual_seed(0)                         # identical parameters on every rank
+    model = FastGRNNCUDA(F, H, device=dev)       # reference init: 0.1*randn, biases 1, zeta 1, nu -4
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(T, B, F, generator=g).to(dev)
+    G = torch.randn(T, B, H, generator=g).to(dev)
+    params = [p for p in model.parameters()]
+    bucket = GradBucket(params, world) if world > 1 else None
+
+    def step():
+        for p in params:
+            p.grad = None
+        hs = model(x)
+        hs.backward(G)                            # L = sum(hs*G): dL/dhs = G
+        if bucket is not None:
+            bucket.all_reduce_()
+
+    for _ in range(args.warmup):
+        step()
+    fastgrnn_cuda._timing = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing, fastgrnn_cuda._timing = fastgrnn_cuda._timing, None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_f = [a.elapsed_time(b) for tag, a, b in timing if tag == "forward"]
+        ms_b = [a.elapsed_time(b) for tag, a, b in timing if tag == "backward"]
+        avg_f = sum(ms_f) / len(ms_f)
+        avg_b = sum(ms_b) / len(ms_b)
+        value = world * B * args.steps / dt
+        path_f = fastgrnn_cuda.kernel_path(T, B, F, H, direction=0)
+        path_b = fastgrnn_cuda.kernel_path(T, B, F, H, direction=1)
+        tf_b = B * FLOPS_BWD / (avg_b * 1e-3) / 1e12
+        tf_f = B * FLOPS_FWD / (avg_f * 1e-3) / 1e12
+        out = {
+            "metric": "utterances/sec fwd+bwd, T=99 feat=32 hidden=128, bs=4096 at 1/2/4/8 GPUs",
+            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FastGRNN dense fwd+bwd training step, T=99 F=32 H=128 B=%d per GPU, fp32, "
+                                   "dense grad_hs, z_s/h_prime_s saved as the reference operator does" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "kernel_path": {"forward": path_f, "backward": path_b}},
+            # dominant kernel = the backward scan (fastgrnn_hip_backward_unroll); the scan's
+            # binding roof at fp32 is the f32 MFMA/FMA rate (intensity ~64 flop/B)
+            "roofline": {"kernel": "backward_unroll", "bound": "mfma", "achieved": tf_b, "peak": PEAK_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf_b / PEAK_F32_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_b, "flops_per_launch": B * FLOPS_BWD},
+            "roofline_hbm": {"kernel": "backward_unroll", "bound": "hbm",
+                             "achieved": B * BYTES_BWD / (avg_b * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None},
+            "forward_kernel": {"avg_launch_ms": avg_f, "tflops": tf_f, "frac_f32_peak": tf_f / PEAK_F32_TFLOPS,
+                               "hbm_gbs": B * BYTES_FWD / (avg_f * 1e-3) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.fastgrnn_torch_port import time_fwd_bwd
+            cores = os.cpu_count() or 1
+            r = time_fwd_bwd(B, T, F, H, threads=cores, budget_s=args.cpu_budget)
+            out["cpu_baseline"] = {"value": r["utt_per_s"], "unit": "utterances/s", "cores": r["threads"],
+                                   "kind": "port",
+                                   "sample": "%d iterations of the full B=%d T=99 fwd+bwd step (torch CPU port of "
+                                             "FastGRNNCell + BaseRNN loop + autograd), median" % (r["iters"], B),
+                                   "fwd_only_value": r["fwd_utt_per_s"]}
+            out["speedup_vs_cpu"] = value / r["utt_per_s"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

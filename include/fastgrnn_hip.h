@@ -1,0 +1,153 @@
+/*
+ * fastgrnn_hip.h -- C ABI of libfastgrnn_hip.so: the MI355X (gfx950) FastGRNN
+ * recurrent cell, forward and backward, single-step and unrolled over T frames.
+ *
+ * This is the drop-in boundary for the reference's native operator module
+ * `fastgrnn_cuda` (/root/reference cuda/fastgrnn_cuda.cpp:235-240), whose four
+ * entry points -- forward, backward, forward_unroll, backward_unroll -- are the
+ * only native calls on the hot path (called from rnn.py:894,903,910,955).
+ *
+ * Conventions (all taken from the reference boundary, file:line cited per item):
+ *   - plain device pointers + sizes; no torch types; the library allocates
+ *     NOTHING and never synchronises: the caller passes outputs and a workspace
+ *     (size from the *_workspace_bytes queries) and a hipStream_t.  Kernels are
+ *     launched on that stream; the stream's device must be current.
+ *   - every tensor is dense row-major ("contiguous", fastgrnn_cuda.cpp:69-71).
+ *   - weight layout is the CUDA classes' [out,in] (rnn.py:783-798):
+ *       w:[H,F]  u:[H,H]  w1:[w_rank,F]  w2:[H,w_rank]  u1:[u_rank,H]  u2:[H,u_rank]
+ *       pre = x . w^T + h . u^T            (.cu:356,361,368)
+ *     low-rank is evaluated FACTORISED, (x.w1^T).w2^T + (h.u1^T).u2^T, the CPU
+ *     cell's association order (rnn.py:280-287); w_rank/u_rank == 0 means dense
+ *     and the unused pointers may be NULL (reference: torch.empty(0),
+ *     rnn.py:783-798, .cu:138-139).
+ *   - zeta and nu are RAW device scalars; sigmoid is applied inside
+ *     (.cu:148-149,364-365) and d_zeta/d_nu are w.r.t. the raw values
+ *     (.cu:116-117).
+ *   - gate code table {sigmoid:0, relu:1, tanh:2} is rnn.py:478,751; codes 3..5
+ *     add the CPU cell's quantTanh/quantSigm/quantSigm4 (rnn.py:53-60).  The
+ *     reference's CUDA path fixes the update nonlinearity to tanh (.cu:57);
+ *     update_nl is exposed because the CPU cell allows it (rnn.py:292-293).
+ *   - every function returns a fastgrnn_status; nonzero means nothing useful
+ *     was launched (argument errors) or the launch itself failed.
+ *   - re-entrant, no global mutable state; safe from the autograd worker thread.
+ */
+#ifndef FASTGRNN_HIP_H
+#define FASTGRNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTGRNN_HIP_ABI_VERSION 1
+
+typedef enum fastgrnn_status {
+  FASTGRNN_OK = 0,
+  FASTGRNN_ERR_NULL_POINTER = 1,   /* a required pointer is NULL */
+  FASTGRNN_ERR_BAD_SHAPE = 2,      /* T,B,F,H < 1, rank < 0, rank > dims, or size overflow */
+  FASTGRNN_ERR_BAD_NONLINEARITY = 3,
+  FASTGRNN_ERR_BAD_DTYPE = 4,
+  FASTGRNN_ERR_WORKSPACE = 5,      /* workspace NULL/too small/misaligned (needs 256 B) */
+  FASTGRNN_ERR_LAUNCH = 6,         /* hipGetLastError() != hipSuccess after a launch */
+  FASTGRNN_ERR_UNSUPPORTED = 7
+} fastgrnn_status;
+
+typedef enum fastgrnn_dtype {
+  FASTGRNN_F32 = 0,                /* mandatory type of the reference (AT_DISPATCH_FLOATING_TYPES, .cu:158) */
+  FASTGRNN_F64 = 1                 /* gradcheck type of the reference dispatch */
+} fastgrnn_dtype;
+
+typedef enum fastgrnn_nonlinearity {
+  FASTGRNN_NL_SIGMOID = 0, FASTGRNN_NL_RELU = 1, FASTGRNN_NL_TANH = 2,       /* rnn.py:478 */
+  FASTGRNN_NL_QUANT_TANH = 3, FASTGRNN_NL_QUANT_SIGM = 4, FASTGRNN_NL_QUANT_SIGM4 = 5 /* rnn.py:53-60 */
+} fastgrnn_nonlinearity;
+
+/* flags */
+#define FASTGRNN_FLAG_FORCE_GENERIC 1u  /* bypass the MFMA-tiled kernels (testing / A-B) */
+
+/* Problem descriptor.  T = 1 for the single-step operators. */
+typedef struct fastgrnn_desc {
+  int32_t T, B, F, H;       /* frames, utterances, features per frame, hidden units */
+  int32_t w_rank, u_rank;   /* 0 = dense */
+  int32_t gate_nl;          /* fastgrnn_nonlinearity */
+  int32_t update_nl;        /* fastgrnn_nonlinearity; the reference CUDA boundary means TANH */
+  int32_t dtype;            /* fastgrnn_dtype */
+  uint32_t flags;
+} fastgrnn_desc;
+
+/* Parameters (device pointers, boundary layout above). */
+typedef struct fastgrnn_params {
+  const void *w, *u;                 /* dense matrices or NULL */
+  const void *w1, *w2, *u1, *u2;     /* factors or NULL */
+  const void *bias_gate;             /* [1,H]  (bias_z) */
+  const void *bias_update;           /* [1,H]  (bias_h_prime) */
+  const void *zeta, *nu;             /* [1,1] raw */
+} fastgrnn_params;
+
+/* Gradient outputs, the 12-tuple of .cu:556 in that order.  d_w/d_u are written
+ * for dense operands, d_w1,d_w2 / d_u1,d_u2 for factorised ones; the others are
+ * ignored and may be NULL (reference returns torch::empty(0), .cu:221-224). */
+typedef struct fastgrnn_grads {
+  void *d_x;            /* [T,B,F] */
+  void *d_bias_gate;    /* [1,H] */
+  void *d_bias_update;  /* [1,H] */
+  void *d_zeta;         /* [1,1] */
+  void *d_nu;           /* [1,1] */
+  void *d_h0;           /* [B,H]  (d_old_h) */
+  void *d_w, *d_u;      /* [H,F], [H,H] */
+  void *d_w1, *d_w2;    /* [w_rank,F], [H,w_rank] */
+  void *d_u1, *d_u2;    /* [u_rank,H], [H,u_rank] */
+} fastgrnn_grads;
+
+int fastgrnn_hip_abi_version(void);
+const char *fastgrnn_hip_status_string(int status);
+
+/* Which kernel family a descriptor dispatches to: 0 = generic LDS/VALU scan,
+ * 1 = MFMA-tiled fp32 scan (16 utterances per workgroup, U in registers).
+ * direction: 0 forward, 1 backward.  Pure function of the descriptor. */
+int fastgrnn_hip_kernel_path(const fastgrnn_desc *d, int direction);
+
+/* Workspace sizes in bytes (0 is a valid answer).  Workspace must be 256-B aligned. */
+size_t fastgrnn_hip_forward_workspace_bytes(const fastgrnn_desc *d);
+size_t fastgrnn_hip_backward_workspace_bytes(const fastgrnn_desc *d);
+
+/* forward_unroll -- replaces fastgrnn_unroll_forward (fastgrnn_cuda.cpp:147-180 ->
+ * .cu:320-415).  x:[T,B,F], h0:[B,H] -> hs:[T,B,H]; z_s,c_s:[T,B,H] are the
+ * reference's z_s / h_prime_s outputs and may be NULL when the caller does not
+ * need them (forward-only use). */
+int fastgrnn_hip_forward_unroll(const fastgrnn_desc *d, const fastgrnn_params *p,
+                                const void *x, const void *h0,
+                                void *hs, void *z_s, void *c_s,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* backward_unroll -- replaces fastgrnn_unroll_backward (fastgrnn_cuda.cpp:182-232 ->
+ * .cu:417-557).  grad_hs:[T,B,H] is dL/d(hs[t]) for every t; z_s,c_s are the
+ * forward's outputs.  Writes every applicable member of *g (overwrites, does not
+ * accumulate). */
+int fastgrnn_hip_backward_unroll(const fastgrnn_desc *d, const fastgrnn_params *p,
+                                 const void *grad_hs, const void *x, const void *hs,
+                                 const void *z_s, const void *c_s, const void *h0,
+                                 const fastgrnn_grads *g,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* forward -- replaces fastgrnn_forward (fastgrnn_cuda.cpp:73-107 -> .cu:123-198).
+ * x:[B,F], old_h:[B,H] -> new_h, z, c each [B,H].  d->T must be 1. */
+int fastgrnn_hip_forward(const fastgrnn_desc *d, const fastgrnn_params *p,
+                         const void *x, const void *old_h,
+                         void *new_h, void *z, void *c,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* backward -- replaces fastgrnn_backward (fastgrnn_cuda.cpp:109-145 -> .cu:200-318).
+ * grad_h:[B,H]; g->d_x is [B,F], g->d_h0 is d_old_h.  d->T must be 1. */
+int fastgrnn_hip_backward(const fastgrnn_desc *d, const fastgrnn_params *p,
+                          const void *grad_h, const void *x, const void *old_h,
+                          const void *z, const void *c,
+                          const fastgrnn_grads *g,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTGRNN_HIP_H */

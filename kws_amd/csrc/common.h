@@ -1,0 +1,64 @@
+// Shared device helpers and internal launcher declarations for libfastgrnn_hip.so.
+// gfx950 only; see include/fastgrnn_hip.h for the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/fastgrnn_hip.h"
+
+namespace fastgrnn {
+
+// ---- nonlinearities (reference table: rnn.py:40-67; device forms .cu:17-40) -------------
+template <typename T> __device__ __forceinline__ T sigmoid_acc(T a);
+template <> __device__ __forceinline__ float sigmoid_acc<float>(float a) { return 1.0f / (1.0f + expf(-a)); }
+template <> __device__ __forceinline__ double sigmoid_acc<double>(double a) { return 1.0 / (1.0 + exp(-a)); }
+template <typename T> __device__ __forceinline__ T tanh_acc(T a);
+template <> __device__ __forceinline__ float tanh_acc<float>(float a) { return tanhf(a); }
+template <> __device__ __forceinline__ double tanh_acc<double>(double a) { return tanh(a); }
+
+template <typename T> __device__ __forceinline__ T act(T a, int nl) {
+  switch (nl) {
+    case FASTGRNN_NL_SIGMOID: return sigmoid_acc<T>(a);
+    case FASTGRNN_NL_RELU: return a > T(0) ? a : T(0);
+    case FASTGRNN_NL_TANH: return tanh_acc<T>(a);
+    case FASTGRNN_NL_QUANT_TANH: return a > T(1) ? T(1) : (a < T(-1) ? T(-1) : a);
+    case FASTGRNN_NL_QUANT_SIGM: { T v = (a + T(1)) / T(2); return v > T(1) ? T(1) : (v < T(0) ? T(0) : v); }
+    default: { T v = (a + T(2)) / T(4); return v > T(1) ? T(1) : (v < T(0) ? T(0) : v); }
+  }
+}
+
+// derivative expressed through the OUTPUT y, as the reference kernels do (.cu:27-40).
+// tanh uses 1-y^2 (the reference's unrolled tanh-gate backward wrongly uses d_sigmoid,
+// .cu:519-521; not reproduced).  relu tests y > 0 (== .cu:33-35 where differentiable).
+template <typename T> __device__ __forceinline__ T dact(T y, int nl) {
+  switch (nl) {
+    case FASTGRNN_NL_SIGMOID: return (T(1) - y) * y;
+    case FASTGRNN_NL_RELU: return y > T(0) ? T(1) : T(0);
+    case FASTGRNN_NL_TANH: return T(1) - y * y;
+    case FASTGRNN_NL_QUANT_TANH: return (y < T(1) && y > T(-1)) ? T(1) : T(0);
+    case FASTGRNN_NL_QUANT_SIGM: return (y < T(1) && y > T(0)) ? T(0.5) : T(0);
+    default: return (y < T(1) && y > T(0)) ? T(0.25) : T(0);
+  }
+}
+
+static inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+// ---- internal launchers (implemented in kernels_generic.hip / kernels_mfma.hip) ---------
+size_t generic_forward_ws(const fastgrnn_desc& d);
+size_t generic_backward_ws(const fastgrnn_desc& d);
+int generic_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
+                    void* hs, void* zs, void* cs, void* ws, hipStream_t s);
+int generic_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
+                     const void* hs, const void* zs, const void* cs, const void* h0,
+                     const fastgrnn_grads& g, void* ws, hipStream_t s);
+
+bool mfma_supported(const fastgrnn_desc& d, int direction);
+size_t mfma_forward_ws(const fastgrnn_desc& d);
+size_t mfma_backward_ws(const fastgrnn_desc& d);
+int mfma_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
+                 void* hs, void* zs, void* cs, void* ws, hipStream_t s);
+int mfma_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
+                  const void* hs, const void* zs, const void* cs, const void* h0,
+                  const fastgrnn_grads& g, void* ws, hipStream_t s);
+
+}  // namespace fastgrnn

@@ -1,0 +1,266 @@
+"""Drop-in for the reference's native operator module ``fastgrnn_cuda``
+(/root/reference cuda/fastgrnn_cuda.cpp:235-240): the same four functions with the
+same positional argument orders and return lists, backed by the C ABI of
+``libfastgrnn_hip.so`` (include/fastgrnn_hip.h).
+
+    forward(input, w, u, bias_gate, bias_update, zeta, nu, old_h, z_non_linearity,
+            w1, w2, u1, u2)                                  -> [new_h, z, h_prime]
+    backward(grad_h, input, old_h, zeta, nu, w, u, z, h_prime, w1, w2, u1, u2,
+             z_non_linearity)                                -> 12 tensors
+    forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, initial_h,
+                   z_non_linearity, w1, w2, u1, u2)          -> [hs, z_s, h_prime_s]
+    backward_unroll(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime,
+                    initial_h, w1, w2, u1, u2, z_non_linearity) -> 12 tensors
+
+(fastgrnn_cuda.cpp:73-232).  The 12-tuple order is
+``d_input, d_bias_z, d_bias_h_prime, d_zeta, d_nu, d_old_h, d_w, d_u, d_w1, d_w2,
+d_u1, d_u2`` (.cu:317,556); operands that do not apply are ``torch.empty(0)`` on both
+sides of the call (rnn.py:783-798, .cu:221-224).
+
+This shim only checks arguments the way ``CHECK_INPUT`` does
+(fastgrnn_cuda.cpp:69-71 -> RuntimeError), allocates outputs + workspace with torch,
+and launches on torch's CURRENT stream of the input's device.  All arithmetic is in
+the HIP kernels; there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+# Optional per-launch timing (bench.py): when set to a list, every C-ABI call appends
+# (tag, start_event, end_event) recorded on the stream the kernels are launched on.
+_timing = None
+
+
+class _Timed:
+    def __init__(self, tag, device):
+        self.tag, self.device = tag, device
+
+    def __enter__(self):
+        if _timing is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.e1.record(torch.cuda.current_stream(self.device))
+            _timing.append((self.tag, self.e0, self.e1))
+        return False
+
+
+def _check_input(t, name):
+    # CHECK_CUDA / CHECK_CONTIGUOUS, fastgrnn_cuda.cpp:69-71
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _present(t):
+    # reference: low-rank is detected by w1.size(0) != 0 (.cu:138-139)
+    return t is not None and t.numel() != 0
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if _present(t) else C.c_void_p(None)
+
+
+def _expect(t, shape, name):
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+
+
+def _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu, dtype, gate_nl,
+              update_nl, flags):
+    """Validate parameters against (F,H) and build the C descriptor + params struct."""
+    if dtype not in _DTYPES:
+        raise RuntimeError("fastgrnn: unsupported dtype %s (float32/float64 only)" % dtype)
+    w_lr, u_lr = _present(w1), _present(u1)
+    if w_lr:
+        _check_input(w1, "w1"); _check_input(w2, "w2")
+        rw = w1.shape[0]
+        _expect(w1, (rw, F), "w1"); _expect(w2, (H, rw), "w2")
+    else:
+        _check_input(w, "w")
+        rw = 0
+        _expect(w, (H, F), "w")
+    if u_lr:
+        _check_input(u1, "u1"); _check_input(u2, "u2")
+        ru = u1.shape[0]
+        _expect(u1, (ru, H), "u1"); _expect(u2, (H, ru), "u2")
+    else:
+        _check_input(u, "u")
+        ru = 0
+        _expect(u, (H, H), "u")
+    for t, n in ((zeta, "zeta"), (nu, "nu")):
+        _check_input(t, n)
+        if t.numel() != 1:
+            raise RuntimeError("%s must hold one element" % n)
+    tensors = [t for t in (w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu) if _present(t)]
+    for t in tensors:
+        if t.dtype != dtype:
+            raise RuntimeError("fastgrnn: all operands must share dtype %s (got %s)" % (dtype, t.dtype))
+    desc = _lib.Desc(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), _DTYPES[dtype], int(flags))
+    params = _lib.Params(_ptr(None if w_lr else w), _ptr(None if u_lr else u),
+                         _ptr(w1 if w_lr else None), _ptr(w2 if w_lr else None),
+                         _ptr(u1 if u_lr else None), _ptr(u2 if u_lr else None),
+                         _ptr(bias_gate), _ptr(bias_update), _ptr(zeta), _ptr(nu))
+    return desc, params, w_lr, u_lr
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None, C.c_void_p(None)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return ws, C.c_void_p(ws.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def kernel_path(T, B, F, H, w_rank=0, u_rank=0, gate_nl=0, update_nl=2, dtype=torch.float32,
+                direction=0, flags=0):
+    """0 = generic scan, 1 = MFMA-tiled scan (pure function of the descriptor)."""
+    desc = _lib.Desc(T, B, F, H, w_rank, u_rank, gate_nl, update_nl, _DTYPES[dtype], flags)
+    return _lib.load().fastgrnn_hip_kernel_path(C.byref(desc), direction)
+
+
+def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1, w2, u1, u2,
+                  unrolled, update_nl, want_gates, flags):
+    lib = _lib.load()
+    _check_input(input, "input")
+    _check_input(bias_gate, "bias_gate"); _check_input(bias_update, "bias_update")
+    _check_input(h0, "initial_h" if unrolled else "old_h")
+    if unrolled:
+        if input.dim() != 3:
+            raise RuntimeError("input must be [timesteps, batch, features]")
+        T, B, F = input.shape
+    else:
+        if input.dim() != 2:
+            raise RuntimeError("input must be [batch, features]")
+        T = 1
+        B, F = input.shape
+    H = h0.shape[-1]
+    _expect(h0, (B, H), "initial_h" if unrolled else "old_h")
+    if bias_gate.numel() != H or bias_update.numel() != H:
+        raise RuntimeError("bias_gate/bias_update must hold H=%d elements" % H)
+    if h0.dtype != input.dtype:
+        raise RuntimeError("input and hidden state dtypes differ")
+    desc, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
+                                   input.dtype, gate_nl, update_nl, flags)
+    dev = input.device
+    oshape = (T, B, H) if unrolled else (B, H)
+    with torch.cuda.device(dev):
+        hs = torch.empty(oshape, dtype=input.dtype, device=dev)
+        zs = torch.empty(oshape, dtype=input.dtype, device=dev) if want_gates else None
+        cs = torch.empty(oshape, dtype=input.dtype, device=dev) if want_gates else None
+        nbytes = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))
+        ws, wsp = _workspace(nbytes, dev)
+        fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
+        with _Timed("forward", dev):
+            st = fn(C.byref(desc), C.byref(params), _ptr(input), _ptr(h0), _ptr(hs), _ptr(zs), _ptr(cs),
+                    wsp, nbytes, _stream(dev))
+        _lib.check(st, "fastgrnn forward_unroll" if unrolled else "fastgrnn forward")
+        # ws was allocated by torch's caching allocator on this same (current) stream, so
+        # its reuse after this function returns is stream-ordered behind the launches above.
+        del ws
+    return [hs, zs, cs] if want_gates else [hs]
+
+
+def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w1, w2, u1, u2, gate_nl,
+                   unrolled, update_nl, flags):
+    lib = _lib.load()
+    for t, n in ((grad_h, "grad_h"), (input, "input"), (hs_or_old_h, "hidden_states" if unrolled else "old_h"),
+                 (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
+        _check_input(t, n)
+    if unrolled:
+        T, B, F = input.shape
+        H = grad_h.shape[-1]
+        _expect(grad_h, (T, B, H), "grad_h"); _expect(hs_or_old_h, (T, B, H), "hidden_states")
+        _expect(z, (T, B, H), "z"); _expect(h_prime, (T, B, H), "h_prime"); _expect(h0, (B, H), "initial_h")
+    else:
+        T = 1
+        B, F = input.shape
+        H = grad_h.shape[-1]
+        _expect(grad_h, (B, H), "grad_h"); _expect(h0, (B, H), "old_h")
+        _expect(z, (B, H), "z"); _expect(h_prime, (B, H), "h_prime")
+    dt = input.dtype
+    for t in (grad_h, hs_or_old_h, z, h_prime, h0):
+        if t.dtype != dt:
+            raise RuntimeError("fastgrnn backward: operand dtypes differ")
+    # biases are not needed by the backward (z, h_prime are given); pass zeta as a dummy
+    desc, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2, zeta, zeta, zeta, nu,
+                                         dt, gate_nl, update_nl, flags)
+    dev = input.device
+    with torch.cuda.device(dev):
+        mk = lambda *s: torch.empty(s, dtype=dt, device=dev)
+        none = lambda: torch.empty(0)
+        d_input = mk(*input.shape)
+        d_bz, d_bh = mk(1, H), mk(1, H)
+        d_zeta, d_nu = mk(1, 1), mk(1, 1)
+        d_old_h = mk(B, H)
+        d_w = none() if w_lr else mk(H, F)
+        d_u = none() if u_lr else mk(H, H)
+        d_w1 = mk(*w1.shape) if w_lr else none()
+        d_w2 = mk(*w2.shape) if w_lr else none()
+        d_u1 = mk(*u1.shape) if u_lr else none()
+        d_u2 = mk(*u2.shape) if u_lr else none()
+        grads = _lib.Grads(_ptr(d_input), _ptr(d_bz), _ptr(d_bh), _ptr(d_zeta), _ptr(d_nu), _ptr(d_old_h),
+                           _ptr(d_w), _ptr(d_u), _ptr(d_w1), _ptr(d_w2), _ptr(d_u1), _ptr(d_u2))
+        nbytes = lib.fastgrnn_hip_backward_workspace_bytes(C.byref(desc))
+        ws, wsp = _workspace(nbytes, dev)
+        with _Timed("backward", dev):
+            if unrolled:
+                st = lib.fastgrnn_hip_backward_unroll(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
+                                                      _ptr(hs_or_old_h), _ptr(z), _ptr(h_prime), _ptr(h0),
+                                                      C.byref(grads), wsp, nbytes, _stream(dev))
+            else:
+                st = lib.fastgrnn_hip_backward(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
+                                               _ptr(h0), _ptr(z), _ptr(h_prime), C.byref(grads), wsp, nbytes,
+                                               _stream(dev))
+        _lib.check(st, "fastgrnn backward_unroll" if unrolled else "fastgrnn backward")
+        # ws was allocated by torch's caching allocator on this same (current) stream, so
+        # its reuse after this function returns is stream-ordered behind the launches above.
+        del ws
+    return [d_input, d_bz, d_bh, d_zeta, d_nu, d_old_h, d_w, d_u, d_w1, d_w2, d_u1, d_u2]
+
+
+# ---- the four reference entry points (fastgrnn_cuda.cpp:235-240) -------------------------
+
+def forward(input, w, u, bias_gate, bias_update, zeta, nu, old_h, z_non_linearity, w1, w2, u1, u2,
+            *, update_non_linearity=2, flags=0):
+    """fastgrnn_cuda.cpp:73-107 -> [new_h, z, h_prime]."""
+    return _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, old_h, z_non_linearity,
+                         w1, w2, u1, u2, False, update_non_linearity, True, flags)
+
+
+def backward(grad_h, input, old_h, zeta, nu, w, u, z, h_prime, w1, w2, u1, u2, z_non_linearity,
+             *, update_non_linearity=2, flags=0):
+    """fastgrnn_cuda.cpp:109-145 -> 12 tensors (.cu:317)."""
+    return _backward_impl(grad_h, input, old_h, zeta, nu, w, u, z, h_prime, old_h, w1, w2, u1, u2,
+                          z_non_linearity, False, update_non_linearity, flags)
+
+
+def forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_non_linearity,
+                   w1, w2, u1, u2, *, update_non_linearity=2, want_gates=True, flags=0):
+    """fastgrnn_cuda.cpp:147-180 -> [hidden_states, z_s, h_prime_s] (each [T,B,H]).
+    ``want_gates=False`` (extension) returns ``[hidden_states]`` only and skips the two
+    extra [T,B,H] stores -- forward-only / inference use."""
+    return _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_non_linearity,
+                         w1, w2, u1, u2, True, update_non_linearity, want_gates, flags)
+
+
+def backward_unroll(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h, w1, w2, u1, u2,
+                    z_non_linearity, *, update_non_linearity=2, flags=0):
+    """fastgrnn_cuda.cpp:182-232 -> 12 tensors (.cu:556)."""
+    return _backward_impl(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h,
+                          w1, w2, u1, u2, z_non_linearity, True, update_non_linearity, flags)

@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's GPU FastGRNN classes (/root/reference rnn.py):
+
+* ``FastGRNNCUDACell``        rnn.py:454-549   single-step cell
+* ``FastGRNNCUDA``            rnn.py:738-889   unrolled module (the class the build sits behind)
+* ``FastGRNNFunction``        rnn.py:891-905   autograd glue, single step
+* ``FastGRNNUnrollFunction``  rnn.py:907-972   autograd glue, unrolled
+
+Same constructor keywords, same parameter names and ``[out,in]`` shapes (so reference
+state dicts ``rnn_list.{l}.W|U|W1|W2|U1|U2|bias_gate|bias_update|zeta|nu`` load), same
+gate-code table, zero ``h0`` default, ``batch_first`` handling and error behaviour, with
+these deliberate differences:
+
+* the GPU gate is ``torch.cuda.is_available()`` (ROCm reports HIP devices there), not
+  ``utils.findCUDA()`` which looks for nvcc (utils.py:12-36);
+* ``device=`` may be passed explicitly (e.g. a specific ``cuda:N`` for one-process-per-GPU
+  data parallel, or ``"cpu"`` to inspect parameter layout without a GPU -- calling
+  ``forward`` on CPU tensors still raises like CHECK_CUDA, fastgrnn_cuda.cpp:69);
+* non-Parameter placeholders for absent operands are registered buffers so ``.to()``
+  keeps them beside the parameters;
+* the tanh-gate backward uses d_tanh (reference defect .cu:519-521 not reproduced).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import fastgrnn_cuda
+
+NON_LINEARITY = {"sigmoid": 0, "relu": 1, "tanh": 2}   # rnn.py:478,751
+
+
+def _resolve_device(device):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        # same message and exception type as rnn.py:476-477,749-750
+        raise Exception('FastGRNNCUDA is supported only on GPU devices.')
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class FastGRNNFunction(Function):
+    """rnn.py:891-905."""
+
+    @staticmethod
+    def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity):
+        outputs = fastgrnn_cuda.forward(input.contiguous(), w, u, bias_gate, bias_update, zeta, nu,
+                                        old_h.contiguous(), gate_non_linearity, w1, w2, u1, u2)
+        new_h = outputs[0]
+        variables = [input, old_h, zeta, nu, w, u] + outputs[1:] + [w1, w2, u1, u2]
+        ctx.save_for_backward(*variables)
+        ctx.non_linearity = gate_non_linearity
+        return new_h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        input, old_h, zeta, nu, w, u, z, h_prime, w1, w2, u1, u2 = ctx.saved_tensors
+        outputs = fastgrnn_cuda.backward(grad_h.contiguous(), input.contiguous(), old_h.contiguous(), zeta, nu,
+                                         w, u, z, h_prime, w1, w2, u1, u2, ctx.non_linearity)
+        return _as_autograd_grads(outputs, ctx.needs_input_grad)
+
+
+class FastGRNNUnrollFunction(Function):
+    """rnn.py:907-972."""
+
+    @staticmethod
+    def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity):
+        input = input.contiguous()
+        old_h = old_h.contiguous()
+        outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
+                                               gate_non_linearity, w1, w2, u1, u2)
+        hidden_states = outputs[0]
+        variables = [input, hidden_states, zeta, nu, w, u] + outputs[1:] + [old_h, w1, w2, u1, u2]
+        ctx.save_for_backward(*variables)
+        ctx.gate_non_linearity = gate_non_linearity
+        return hidden_states
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
+        outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
+                                                z_s, h_prime_s, old_h, w1, w2, u1, u2,
+                                                ctx.gate_non_linearity)
+        return _as_autograd_grads(outputs, ctx.needs_input_grad)
+
+
+def _as_autograd_grads(outputs, needs):
+    """Map the operator's 12-tuple (.cu:556) onto the Function's 13 inputs
+    (input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, nl):
+    same order + trailing None (rnn.py:905,972); empty(0) placeholders become None."""
+    grads = []
+    for g, need in zip(outputs, needs[:12]):
+        grads.append(g if (need and g.numel() != 0) else None)
+    return tuple(grads + [None])
+
+
+def _make_params(mod, input_size, hidden_size, wRank, uRank, zetaInit, nuInit, device):
+    """Parameter set of rnn.py:491-517 / 782-805: [out,in] layout, 0.1*randn, biases one."""
+    if wRank is None:
+        mod.W = nn.Parameter(0.1 * torch.randn([hidden_size, input_size], device=device))
+        mod.register_buffer("W1", torch.empty(0), persistent=False)
+        mod.register_buffer("W2", torch.empty(0), persistent=False)
+    else:
+        mod.register_buffer("W", torch.empty(0), persistent=False)
+        mod.W1 = nn.Parameter(0.1 * torch.randn([wRank, input_size], device=device))
+        mod.W2 = nn.Parameter(0.1 * torch.randn([hidden_size, wRank], device=device))
+    if uRank is None:
+        mod.U = nn.Parameter(0.1 * torch.randn([hidden_size, hidden_size], device=device))
+        mod.register_buffer("U1", torch.empty(0), persistent=False)
+        mod.register_buffer("U2", torch.empty(0), persistent=False)
+    else:
+        mod.register_buffer("U", torch.empty(0), persistent=False)
+        mod.U1 = nn.Parameter(0.1 * torch.randn([uRank, hidden_size], device=device))
+        mod.U2 = nn.Parameter(0.1 * torch.randn([hidden_size, uRank], device=device))
+    mod.bias_gate = nn.Parameter(torch.ones([1, hidden_size], device=device))
+    mod.bias_update = nn.Parameter(torch.ones([1, hidden_size], device=device))
+    mod.zeta = nn.Parameter(zetaInit * torch.ones([1, 1], device=device))
+    mod.nu = nn.Parameter(nuInit * torch.ones([1, 1], device=device))
+
+
+def _get_vars(mod):
+    # rnn.py:536-549, 828-841
+    Vars = []
+    if mod._num_W_matrices == 1:
+        Vars.append(mod.W)
+    else:
+        Vars.extend([mod.W1, mod.W2])
+    if mod._num_U_matrices == 1:
+        Vars.append(mod.U)
+    else:
+        Vars.extend([mod.U1, mod.U2])
+    Vars.extend([mod.bias_gate, mod.bias_update, mod.zeta, mod.nu])
+    return Vars
+
+
+class FastGRNNCUDACell(nn.Module):
+    """Single-step GPU cell (rnn.py:454-549).
+
+    z_t = non_linearity(W x_t + U h_{t-1} + B_g);  h_t^ = tanh(W x_t + U h_{t-1} + B_h)
+    h_t = z_t*h_{t-1} + (sigmoid(zeta)(1-z_t) + sigmoid(nu))*h_t^
+    """
+
+    def __init__(self, input_size, hidden_size, gate_nonlinearity="sigmoid",
+                 update_nonlinearity="tanh", wRank=None, uRank=None, zetaInit=1.0, nuInit=-4.0,
+                 wSparsity=1.0, uSparsity=1.0, name="FastGRNNCUDACell", device=None):
+        super().__init__()
+        self.device = _resolve_device(device)
+        if update_nonlinearity != "tanh":
+            raise ValueError("FastGRNNCUDA fixes update_nonlinearity to tanh (rnn.py:741-742)")
+        self._input_size = input_size
+        self._hidden_size = hidden_size
+        self._gate_nonlinearity = gate_nonlinearity
+        self._update_nonlinearity = update_nonlinearity
+        self._zetaInit = zetaInit
+        self._nuInit = nuInit
+        self._name = name
+        self._wRank, self._uRank = wRank, uRank
+        self._wSparsity, self._uSparsity = wSparsity, uSparsity
+        self._num_W_matrices = 1 if wRank is None else 2
+        self._num_U_matrices = 1 if uRank is None else 2
+        self._num_biases = 2
+        self._num_weight_matrices = [self._num_W_matrices, self._num_U_matrices, self._num_biases]
+        _make_params(self, input_size, hidden_size, wRank, uRank, zetaInit, nuInit, self.device)
+        self._gate_non_linearity = NON_LINEARITY[gate_nonlinearity]   # KeyError on others, as rnn.py:512
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def cellType(self):
+        return "FastGRNNCUDACell"
+
+    @property
+    def state_size(self):
+        return self._hidden_size
+
+    @property
+    def input_size(self):
+        return self._input_size
+
+    @property
+    def output_size(self):
+        return self._hidden_size
+
+    def forward(self, input, state):
+        return FastGRNNFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu, state,
+                                      self.W, self.U, self.W1, self.W2, self.U1, self.U2,
+                                      self._gate_non_linearity)
+
+    def getVars(self):
+        return _get_vars(self)
+
+
+class FastGRNNCUDA(nn.Module):
+    """Unrolled GPU FastGRNN (rnn.py:738-889).  ``update_nonlinearity`` is fixed to tanh,
+    only ``gate_nonlinearity`` is configurable (rnn.py:741-742)."""
+
+    def __init__(self, input_size, hidden_size, gate_nonlinearity="sigmoid",
+                 update_nonlinearity="tanh", wRank=None, uRank=None,
+                 wSparsity=1.0, uSparsity=1.0, zetaInit=1.0, nuInit=-4.0,
+                 batch_first=False, name="FastGRNNCUDA", device=None):
+        super().__init__()
+        self.device = _resolve_device(device)
+        if update_nonlinearity != "tanh":
+            raise ValueError("FastGRNNCUDA fixes update_nonlinearity to tanh (rnn.py:741-742)")
+        self._input_size = input_size
+        self._hidden_size = hidden_size
+        self._zetaInit = zetaInit
+        self._nuInit = nuInit
+        self._name = name
+        self._wRank, self._uRank = wRank, uRank
+        self._wSparsity, self._uSparsity = wSparsity, uSparsity
+        self._num_W_matrices = 1 if wRank is None else 2
+        self._num_U_matrices = 1 if uRank is None else 2
+        self._num_biases = 2
+        self._num_weight_matrices = [self._num_W_matrices, self._num_U_matrices, self._num_biases]
+        self.oldmats = []
+        self.batch_first = batch_first
+        _make_params(self, input_size, hidden_size, wRank, uRank, zetaInit, nuInit, self.device)
+        self._gate_non_linearity = NON_LINEARITY[gate_nonlinearity]
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.device = self.bias_gate.device
+        return out
+
+    def forward(self, input, hiddenState=None, cell_state=None):
+        """input: [timesteps, batch, features] (or [batch, timesteps, features] when
+        ``batch_first``); hiddenState: [batch, state_size], zeros if not provided
+        (rnn.py:807-826).  Returns every hidden state, same leading layout as the input."""
+        if self.batch_first is True:
+            input = input.transpose(0, 1).contiguous()
+        if not input.is_cuda:
+            input = input.to(self.device)
+        if hiddenState is None:
+            hiddenState = torch.zeros([input.shape[1], self._hidden_size], dtype=input.dtype,
+                                      device=input.device)
+        if not hiddenState.is_cuda:
+            hiddenState = hiddenState.to(self.device)
+        result = FastGRNNUnrollFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu,
+                                              hiddenState, self.W, self.U, self.W1, self.W2, self.U1, self.U2,
+                                              self._gate_non_linearity)
+        if self.batch_first is True:
+            return result.transpose(0, 1)
+        return result
+
+    def getVars(self):
+        return _get_vars(self)

@@ -1,0 +1,134 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, and its host-only functions (status strings, path selection, workspace sizes,
+argument validation) behave.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from kws_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "fastgrnn_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fastgrnn_hip_\w+)\s*\(", hdr)))
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) == set(_lib.EXPORTS)
+
+
+def test_abi_version_and_status_strings(lib):
+    assert lib.fastgrnn_hip_abi_version() == 1
+    assert _lib.status_string(0) == "ok"
+    for code in range(1, 8):
+        assert _lib.status_string(code) not in ("ok", "unknown status")
+    assert _lib.status_string(99) == "unknown status"
+
+
+def _desc(**kw):
+    base = dict(T=99, B=4096, F=32, H=128, w_rank=0, u_rank=0, gate_nl=0, update_nl=2, dtype=0, flags=0)
+    base.update(kw)
+    return _lib.Desc(**base)
+
+
+def test_kernel_path_is_pure_and_respects_force_generic(lib):
+    d = _desc()
+    a = lib.fastgrnn_hip_kernel_path(C.byref(d), 0)
+    assert a in (0, 1) and a == lib.fastgrnn_hip_kernel_path(C.byref(d), 0)
+    d2 = _desc(flags=_lib.FLAG_FORCE_GENERIC)
+    assert lib.fastgrnn_hip_kernel_path(C.byref(d2), 0) == 0
+    assert lib.fastgrnn_hip_kernel_path(C.byref(d2), 1) == 0
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(dtype=1)), 0) == 0      # fp64 -> generic
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=20, F=7)), 0) == 0     # odd shape -> generic
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(T=0)), 0) == -1
+
+
+def test_workspace_queries(lib):
+    d = _desc(flags=_lib.FLAG_FORCE_GENERIC)
+    fw = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(d))
+    bw = lib.fastgrnn_hip_backward_workspace_bytes(C.byref(d))
+    assert fw >= (32 * 128 + 128 * 128) * 4 and fw % 256 == 0
+    assert bw >= 99 * 4096 * 128 * 4 and bw % 256 == 0
+    assert lib.fastgrnn_hip_forward_workspace_bytes(C.byref(_desc(B=0))) == 0
+
+
+def test_argument_validation_without_launch(lib):
+    """Bad arguments are rejected before anything touches the GPU."""
+    null = C.c_void_p(None)
+    d = _desc(B=4, T=3)
+    p = _lib.Params()
+    # NULL params / tensors
+    st = lib.fastgrnn_hip_forward_unroll(C.byref(d), C.byref(p), null, null, null, null, null, null, 0, null)
+    assert st == 1
+    st = lib.fastgrnn_hip_forward_unroll(C.byref(_desc(H=0)), C.byref(p), null, null, null, null, null, null, 0, null)
+    assert st == 2
+    st = lib.fastgrnn_hip_forward_unroll(C.byref(_desc(gate_nl=9)), C.byref(p), null, null, null, null, null, null, 0, null)
+    assert st == 3
+    st = lib.fastgrnn_hip_forward_unroll(C.byref(_desc(dtype=5)), C.byref(p), null, null, null, null, null, null, 0, null)
+    assert st == 4
+    # single-step entry points insist on T == 1
+    st = lib.fastgrnn_hip_forward(C.byref(d), C.byref(p), null, null, null, null, null, null, 0, null)
+    assert st == 2
+    # workspace too small: fake non-null pointers, valid desc -> must fail on the workspace check
+    one = C.c_void_p(256)
+    pf = _lib.Params(*([one] * 10))
+    dg = _desc(B=4, T=3, flags=_lib.FLAG_FORCE_GENERIC)
+    st = lib.fastgrnn_hip_forward_unroll(C.byref(dg), C.byref(pf), one, one, one, null, null, null, 0, null)
+    assert st == 5
+    g = _lib.Grads()
+    st = lib.fastgrnn_hip_backward_unroll(C.byref(dg), C.byref(pf), one, one, one, one, one, one, C.byref(g), null, 0, null)
+    assert st == 1
+
+
+def test_module_parameter_layout_matches_reference_classes():
+    """rnn.py:782-805: [out,in] shapes and state-dict key names."""
+    from kws_amd import FastGRNNCUDA, FastGRNNCUDACell
+    m = FastGRNNCUDA(32, 128, device="cpu")
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sd == {"W": (128, 32), "U": (128, 128), "bias_gate": (1, 128), "bias_update": (1, 128),
+                  "zeta": (1, 1), "nu": (1, 1)}
+    assert float(m.zeta) == 1.0 and float(m.nu) == -4.0 and float(m.bias_gate.min()) == 1.0
+    m = FastGRNNCUDA(32, 256, wRank=16, uRank=16, device="cpu")
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sd["W1"] == (16, 32) and sd["W2"] == (256, 16) and sd["U1"] == (16, 256) and sd["U2"] == (256, 16)
+    assert "W" not in sd and "U" not in sd
+    assert m.W.numel() == 0 and m.U.numel() == 0
+    assert [tuple(v.shape) for v in m.getVars()] == [(16, 32), (256, 16), (16, 256), (256, 16), (1, 256), (1, 256), (1, 1), (1, 1)]
+    c = FastGRNNCUDACell(32, 128, gate_nonlinearity="tanh", device="cpu")
+    assert c._gate_non_linearity == 2 and c.cellType == "FastGRNNCUDACell"
+    with pytest.raises(KeyError):
+        FastGRNNCUDA(32, 128, gate_nonlinearity="quantSigm", device="cpu")
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from kws_amd import FastGRNNCUDA
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception, match="supported only on GPU"):
+        FastGRNNCUDA(32, 128)
+    m = FastGRNNCUDA(32, 128, device="cpu")
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        m(torch.randn(3, 2, 32))
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure; nothing under kws_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "kws_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("test oracle", ""), os.path.join(dirpath, f)

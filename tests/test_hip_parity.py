@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path (through the C ABI via kws_amd.fastgrnn_cuda) against
+(a) the committed golden vectors produced by the reference's own CPU cell and
+(b) the numpy oracle on seeded inputs, plus size-independent properties at the
+BASELINE.json sizes.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (north_star: 1e-5 fp32 against the reference's CPU path):
+  * hidden states fp32: max|d| <= 1e-5 absolute (|h| <~ 2).
+  * gradients fp32: max|d| / max(1, max|ref|) <= 2e-5.  Gradients are sums over up to
+    T*B terms whose fp32 summation order differs from ATen's; the reference's own fp32
+    CPU result differs from its fp64 result by the same order (checked below).
+  * fp64: 1e-12 / 1e-10.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fastgrnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from kws_amd import FastGRNNCUDA, FastGRNNCUDACell, _lib, fastgrnn_cuda
+DEV = "cuda:0"
+
+GATE_CODE = {"sigmoid": 0, "relu": 1, "tanh": 2, "quantTanh": 3, "quantSigm": 4, "quantSigm4": 5}
+FORCE_GENERIC = 1
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _param_tensors(p):
+    e = torch.empty(0)
+    g = lambda k: _t(p[k]) if k in p else e
+    return dict(w=g("w"), u=g("u"), w1=g("w1"), w2=g("w2"), u1=g("u1"), u2=g("u2"),
+                bias_gate=_t(p["bias_gate"]), bias_update=_t(p["bias_update"]), zeta=_t(p["zeta"]), nu=_t(p["nu"]))
+
+
+def run_hip(x, h0, G, p, gate="sigmoid", update="tanh", flags=0):
+    """forward_unroll + backward_unroll through the operator module; numpy in/out."""
+    P = _param_tensors(p)
+    xt, ht, Gt = _t(x), _t(h0), _t(G)
+    hs, zs, cs = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"],
+                                              P["nu"], ht, GATE_CODE[gate], P["w1"], P["w2"], P["u1"], P["u2"],
+                                              update_non_linearity=GATE_CODE[update], flags=flags)
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], zs, cs, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], GATE_CODE[gate],
+                                         update_non_linearity=GATE_CODE[update], flags=flags)
+    torch.cuda.synchronize()
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: o.cpu().numpy() for n, o in zip(names, outs) if o.numel()}
+    return hs.cpu().numpy(), zs.cpu().numpy(), cs.cpu().numpy(), g
+
+
+def _check_grads(g, ref, tol, tag):
+    for k, v in ref.items():
+        scale = max(1.0, float(np.abs(v).max()))
+        err = float(np.abs(g[k].reshape(v.shape) - v).max()) / scale
+        assert err <= tol, (tag, k, err)
+
+
+@pytest.mark.parametrize("flags", [0, FORCE_GENERIC], ids=["dispatch", "generic"])
+def test_golden_vectors(golden, flags):
+    """HIP vs the reference CPU cell's own outputs (tests/golden/*.npz)."""
+    f64 = golden["dtype"] == "f64"
+    hs, zs, cs, g = run_hip(golden["x"], golden["h0"], golden["G"], golden["params"],
+                            golden["gate"], golden["update"], flags)
+    assert np.abs(hs - golden["hs"]).max() <= (1e-12 if f64 else 1e-5), golden["name"]
+    ref = dict(golden["dparams"]); ref["d_x"] = golden["dx"]; ref["d_h0"] = golden["dh0"]
+    _check_grads(g, ref, 1e-10 if f64 else 2e-5, golden["name"])
+
+
+CASES = [
+    # T, B, F, H, rw, ru, gate
+    (99, 64, 32, 128, 0, 0, "sigmoid"),     # config (1) plumbing shape
+    (99, 50, 32, 128, 0, 0, "tanh"),        # ragged against the 16-utterance tile
+    (17, 33, 32, 128, 0, 0, "relu"),
+    (99, 32, 32, 256, 16, 16, "sigmoid"),   # config (4) shape, small batch
+    (9, 5, 13, 24, 0, 3, "sigmoid"),
+    (9, 5, 13, 24, 4, 0, "relu"),
+    (3, 1, 1, 1, 0, 0, "sigmoid"),          # degenerate sizes
+    (1, 7, 32, 128, 0, 0, "sigmoid"),       # T = 1
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "T%dB%dF%dH%dr%d-%d%s" % c)
+@pytest.mark.parametrize("flags", [0, FORCE_GENERIC], ids=["dispatch", "generic"])
+def test_seeded_vs_oracle_fp32(case, flags):
+    T, B, F, H, rw, ru, gate = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    p = O.make_params(F, H, rw or None, ru or None, np.float32, seed=11, randomize_scalars=True)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    hs, zs, cs, g = run_hip(x, h0, G, p, gate, flags=flags)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
+    g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64,
+                            h0.astype(np.float64), gate=gate)
+    assert np.abs(hs - hs_o).max() <= 1e-5
+    assert np.abs(zs - zs_o).max() <= 1e-5 and np.abs(cs - cs_o).max() <= 1e-5
+    if gate == "relu":
+        # a relu gate is discontinuous in its derivative: fp32-vs-fp64 sign flips of
+        # pre-activations within 1e-6 of zero change d_pre by O(1); compare against the
+        # oracle run in fp32 on the HIP path's own z (same mask) instead.
+        g_o = O.unroll_backward(G, x, hs, zs, cs, p, h0, gate=gate)
+        _check_grads(g, {k: v for k, v in g_o.items()}, 5e-5, case)
+    else:
+        _check_grads(g, g_o, 2e-5, case)
+
+
+@pytest.mark.parametrize("lowrank", [False, True])
+def test_seeded_vs_oracle_fp64(lowrank):
+    T, B, F, H = 12, 9, 10, 24
+    rng = np.random.default_rng(3)
+    p = O.make_params(F, H, 4 if lowrank else None, 5 if lowrank else None, np.float64, seed=5, randomize_scalars=True)
+    x = rng.standard_normal((T, B, F)); h0 = 0.5 * rng.standard_normal((B, H)); G = rng.standard_normal((T, B, H))
+    hs, zs, cs, g = run_hip(x, h0, G, p)
+    hs_o, zs_o, cs_o = O.unroll_forward(x, p, h0)
+    g_o = O.unroll_backward(G, x, hs_o, zs_o, cs_o, p, h0)
+    assert np.abs(hs - hs_o).max() <= 1e-12
+    _check_grads(g, g_o, 1e-10, "fp64")
+
+
+def test_single_step_operators():
+    """forward / backward (fastgrnn_cuda.cpp:73-145) == T=1 oracle."""
+    B, F, H = 37, 32, 128
+    rng = np.random.default_rng(8)
+    p = O.make_params(F, H, dtype=np.float32, seed=2, randomize_scalars=True)
+    x = rng.standard_normal((B, F)).astype(np.float32)
+    h = rng.standard_normal((B, H)).astype(np.float32)
+    G = rng.standard_normal((B, H)).astype(np.float32)
+    P = _param_tensors(p)
+    new_h, z, c = fastgrnn_cuda.forward(_t(x), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"],
+                                        _t(h), 0, P["w1"], P["w2"], P["u1"], P["u2"])
+    outs = fastgrnn_cuda.backward(_t(G), _t(x), _t(h), P["zeta"], P["nu"], P["w"], P["u"], z, c,
+                                  P["w1"], P["w2"], P["u1"], P["u2"], 0)
+    assert len(outs) == 12 and outs[8].numel() == 0 and outs[6].shape == (H, F) and outs[0].shape == (B, F)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x[None].astype(np.float64), p64, h.astype(np.float64))
+    g_o = O.unroll_backward(G[None].astype(np.float64), x[None].astype(np.float64), hs_o, zs_o, cs_o, p64, h.astype(np.float64))
+    assert np.abs(new_h.cpu().numpy() - hs_o[0]).max() <= 1e-5
+    assert np.abs(outs[0].cpu().numpy() - g_o["d_x"][0]).max() <= 2e-5
+    assert np.abs(outs[5].cpu().numpy() - g_o["d_h0"]).max() <= 2e-5
+    assert np.abs(outs[7].cpu().numpy() - g_o["d_u"]).max() <= 2e-5 * max(1, np.abs(g_o["d_u"]).max())
+
+
+def _copy_params(m, p):
+    with torch.no_grad():
+        for k, attr in (("w", "W"), ("u", "U"), ("w1", "W1"), ("w2", "W2"), ("u1", "U1"), ("u2", "U2"),
+                        ("bias_gate", "bias_gate"), ("bias_update", "bias_update"), ("zeta", "zeta"), ("nu", "nu")):
+            if k in p:
+                getattr(m, attr).copy_(torch.from_numpy(p[k]))
+
+
+@pytest.mark.parametrize("batch_first", [False, True])
+@pytest.mark.parametrize("lowrank", [False, True])
+def test_module_autograd_matches_cpu_port(batch_first, lowrank):
+    """FastGRNNCUDA (rnn.py:738-826) forward+autograd vs the torch CPU port of
+    FastGRNNCell + BaseRNN loop (the reference's CPU path)."""
+    from oracle.fastgrnn_torch_port import FastGRNNCellPort, unroll
+    T, B, F, H = 30, 21, 32, 128
+    torch.manual_seed(0)
+    rw = ru = 8 if lowrank else None
+    cell = FastGRNNCellPort(F, H, wRank=rw, uRank=ru)
+    with torch.no_grad():
+        cell.bias_gate.add_(0.3 * torch.randn_like(cell.bias_gate)); cell.zeta.fill_(0.4); cell.nu.fill_(-3.0)
+    m = FastGRNNCUDA(F, H, wRank=rw, uRank=ru, batch_first=batch_first, device=DEV)
+    with torch.no_grad():
+        if lowrank:
+            m.W1.copy_(cell.W1.t()); m.W2.copy_(cell.W2.t()); m.U1.copy_(cell.U1.t()); m.U2.copy_(cell.U2.t())
+        else:
+            m.W.copy_(cell.W.t()); m.U.copy_(cell.U.t())
+        m.bias_gate.copy_(cell.bias_gate); m.bias_update.copy_(cell.bias_update)
+        m.zeta.copy_(cell.zeta); m.nu.copy_(cell.nu)
+    x = torch.randn(T, B, F)
+    G = torch.randn(T, B, H)
+    xc = x.clone().requires_grad_(True)
+    hs_c = unroll(cell, xc)
+    (hs_c * G).sum().backward()
+    xg = (x.transpose(0, 1).contiguous() if batch_first else x).to(DEV).requires_grad_(True)
+    hs_g = m(xg)
+    Gg = (G.transpose(0, 1) if batch_first else G).to(DEV)
+    (hs_g * Gg).sum().backward()
+    hs_gn = hs_g.detach().cpu()
+    if batch_first:
+        assert hs_gn.shape == (B, T, H)
+        hs_gn = hs_gn.transpose(0, 1)
+    assert (hs_gn - hs_c.detach()).abs().max() <= 1e-5
+    dx = xg.grad.cpu()
+    if batch_first:
+        dx = dx.transpose(0, 1)
+    assert (dx - xc.grad).abs().max() <= 2e-5
+    pairs = ([(m.W1, cell.W1), (m.W2, cell.W2), (m.U1, cell.U1), (m.U2, cell.U2)] if lowrank
+             else [(m.W, cell.W), (m.U, cell.U)])
+    for a, b in pairs:
+        scale = max(1.0, float(b.grad.abs().max()))
+        assert (a.grad.cpu() - b.grad.t()).abs().max() / scale <= 2e-5
+    for a, b in ((m.bias_gate, cell.bias_gate), (m.bias_update, cell.bias_update), (m.zeta, cell.zeta), (m.nu, cell.nu)):
+        scale = max(1.0, float(b.grad.abs().max()))
+        assert (a.grad.cpu() - b.grad).abs().max() / scale <= 2e-5
+
+
+def test_cell_module_single_step_autograd():
+    B, F, H = 8, 32, 128
+    torch.manual_seed(1)
+    c = FastGRNNCUDACell(F, H, device=DEV)
+    x = torch.randn(B, F, device=DEV, requires_grad=True)
+    h = torch.randn(B, H, device=DEV, requires_grad=True)
+    out = c(x, h)
+    out.sum().backward()
+    W, U = c.W.detach().cpu().double(), c.U.detach().cpu().double()
+    xd, hd = x.detach().cpu().double(), h.detach().cpu().double()
+    pre = xd @ W.t() + hd @ U.t()
+    z = torch.sigmoid(pre + 1.0); cc = torch.tanh(pre + 1.0)
+    ref = z * hd + (torch.sigmoid(torch.tensor(1.0).double()) * (1 - z) + torch.sigmoid(torch.tensor(-4.0).double())) * cc
+    assert (out.detach().cpu().double() - ref).abs().max() <= 1e-5
+    assert x.grad is not None and h.grad is not None and c.U.grad.shape == (H, H)
+
+
+def test_error_behaviour_mirrors_check_input():
+    """fastgrnn_cuda.cpp:69-71: non-CUDA / non-contiguous operands raise RuntimeError."""
+    F, H, T, B = 32, 128, 4, 6
+    p = O.make_params(F, H)
+    P = _param_tensors(p)
+    x = torch.randn(T, B, F, device=DEV)
+    h0 = torch.zeros(B, H, device=DEV)
+    args = lambda xx, hh: (xx, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], hh, 0,
+                           P["w1"], P["w2"], P["u1"], P["u2"])
+    with pytest.raises(RuntimeError, match="contiguous"):
+        fastgrnn_cuda.forward_unroll(*args(torch.randn(B, T, F, device=DEV).transpose(0, 1), h0))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        fastgrnn_cuda.forward_unroll(*args(x.cpu(), h0))
+    with pytest.raises(RuntimeError, match="shape"):
+        fastgrnn_cuda.forward_unroll(*args(x, torch.zeros(B + 1, H, device=DEV)))
+    with pytest.raises(RuntimeError, match="nonlinearity"):
+        fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 17,
+                                     P["w1"], P["w2"], P["u1"], P["u2"])
+
+
+def test_runs_on_current_stream_and_is_reentrant():
+    """Launches go to torch's current stream (reference used the legacy default stream,
+    SURVEY section 0.5): two side streams produce the same result as the default stream."""
+    T, B, F, H = 20, 40, 32, 128
+    p = O.make_params(F, H, seed=4)
+    P = _param_tensors(p)
+    x = torch.randn(T, B, F, device=DEV)
+    h0 = torch.zeros(B, H, device=DEV)
+    call = lambda: fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"],
+                                                P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])[0]
+    base = call()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            outs.append(call())
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, base)
+
+
+# ---- BASELINE.json sizes: size-independent properties --------------------------------------
+
+def _northstar(B, seed=0):
+    T, F, H = 99, 32, 128
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(DEV)
+    p = O.make_params(F, H, seed=seed)
+    return x, G, p, _param_tensors(p)
+
+
+def _fwd(x, P, h0=None, flags=0):
+    h0 = torch.zeros(x.shape[1], P["u"].shape[0] if P["u"].numel() else P["u2"].shape[0], device=DEV) if h0 is None else h0
+    return fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+
+
+def _bwd(G, x, hs, zs, cs, P, h0, flags=0):
+    return fastgrnn_cuda.backward_unroll(G, x, hs, P["zeta"], P["nu"], P["w"], P["u"], zs, cs, h0,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags)
+
+
+def test_full_size_batch_independence_and_generic_agreement():
+    """B=4096 (config 2): every utterance's hidden states are independent of its batch
+    neighbours (bitwise vs a re-run on a ragged slice), the dispatched path agrees with
+    the generic path, and a sampled slice agrees with the fp64 oracle."""
+    B = 4096
+    x, G, p, P = _northstar(B)
+    hs, zs, cs = _fwd(x, P)
+    lo, hi = 1003, 1003 + 45
+    hs_s, _, _ = _fwd(x[:, lo:hi].contiguous(), P)
+    assert torch.equal(hs[:, lo:hi], hs_s)
+    hs_g, zs_g, cs_g = _fwd(x, P, flags=FORCE_GENERIC)
+    assert (hs - hs_g).abs().max() <= 1e-5
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, _, _ = O.unroll_forward(x[:, lo:hi].cpu().numpy().astype(np.float64), p64)
+    assert np.abs(hs[:, lo:hi].cpu().numpy() - hs_o).max() <= 1e-5
+
+
+def test_full_size_backward_linearity_and_shard_sum():
+    """B=4096 (metric shape): backward is linear in grad_hs, and parameter gradients of
+    the whole batch equal the sum over two batch shards (the data-parallel identity of
+    SURVEY section 8e); d_x of a shard equals the shard of d_x."""
+    B = 4096
+    x, G, p, P = _northstar(B, seed=1)
+    h0 = torch.zeros(B, 128, device=DEV)
+    hs, zs, cs = _fwd(x, P, h0)
+    g1 = _bwd(G, x, hs, zs, cs, P, h0)
+    g2 = _bwd(2.0 * G, x, hs, zs, cs, P, h0)
+    for a, b in zip(g1, g2):
+        if a.numel():
+            assert (2.0 * a - b).abs().max() <= 1e-4 * max(1.0, float(b.abs().max()))
+    half = B // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, B)):
+        xs = x[:, sl].contiguous(); Gs = G[:, sl].contiguous(); hz = h0[sl].contiguous()
+        hs_s, zs_s, cs_s = _fwd(xs, P, hz)
+        parts.append(_bwd(Gs, xs, hs_s, zs_s, cs_s, P, hz))
+    for i in (1, 2, 3, 4, 6, 7):   # d_bias_z, d_bias_h, d_zeta, d_nu, d_w, d_u
+        s = parts[0][i] + parts[1][i]
+        assert (s - g1[i]).abs().max() <= 2e-5 * max(1.0, float(g1[i].abs().max())), i
+    assert torch.allclose(torch.cat([parts[0][0], parts[1][0]], 1), g1[0], atol=1e-6, rtol=0)
+    # against the generic path
+    gg = _bwd(G, x, hs, zs, cs, P, h0, flags=FORCE_GENERIC)
+    for a, b in zip(g1, gg):
+        if a.numel():
+            assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_lowrank_config4_shape_vs_oracle_sample():
+    """config (4): H=256, wRank=uRank=16, B=4096; sampled utterances vs fp64 oracle."""
+    T, B, F, H, r = 99, 4096, 32, 256, 16
+    p = O.make_params(F, H, r, r, seed=9)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    hs, zs, cs = _fwd(x, P)
+    idx = [0, 17, 2048, 4095]
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, _, _ = O.unroll_forward(x[:, idx].cpu().numpy().astype(np.float64), p64)
+    assert np.abs(hs[:, idx].cpu().numpy() - hs_o).max() <= 1e-5
