@@ -1,0 +1,122 @@
+"""Data-parallel path (kws_amd/dp.py) on CPU with gloo, world_size 2.
+
+The DP harness is backend-agnostic host logic (sharding, one flattened bucket, one
+all-reduce, unflatten); on the GPU box the same code runs over RCCL.  The compute
+injected here is the torch CPU port from oracle/ (tests may use the oracle as the
+checker/stand-in; the product's compute path is HIP only).  Identity checked
+(SURVEY.md section 8e): all-reduced gradients of the 2 shards == single-process gradients
+of the whole batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _PortModule(torch.nn.Module):
+    """FastGRNNCUDA-shaped callable backed by the CPU port (x:[T,B,F] -> hs:[T,B,H])."""
+
+    def __init__(self, F, H, wRank=None, uRank=None):
+        super().__init__()
+        from oracle.fastgrnn_torch_port import FastGRNNCellPort
+        self.cell = FastGRNNCellPort(F, H, wRank=wRank, uRank=uRank)
+
+    def forward(self, x, h0=None):
+        from oracle.fastgrnn_torch_port import unroll
+        return unroll(self.cell, x, h0)
+
+
+def _worker(rank, world, port, lowrank, ragged, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kws_amd.dp import GradBucket, data_parallel_step, shard_batch, shard_range
+        torch.set_num_threads(1)
+        T, B, F, H = 7, (9 if ragged else 8), 5, 12
+        torch.manual_seed(0)                      # same replica everywhere
+        r = 3 if lowrank else None
+        model = _PortModule(F, H, r, r).double()
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(T, B, F, generator=g, dtype=torch.float64)
+        G = torch.randn(T, B, H, generator=g, dtype=torch.float64)
+        params = list(model.parameters())
+        bucket = GradBucket(params, world, divisor=1)       # keep the SUM: gradient of the summed loss
+        xs, Gs = shard_batch(x, rank, world), shard_batch(G, rank, world)
+        lo, hi = shard_range(B, rank, world)
+        assert xs.shape[1] == hi - lo
+        hs_local = data_parallel_step(model, xs, Gs, bucket)
+        dp_grads = [p.grad.clone() for p in params]
+        # single-process reference on the whole batch
+        for p in params:
+            p.grad = None
+        hs_full = model(x)
+        hs_full.backward(G)
+        ok = torch.allclose(hs_local, hs_full[:, lo:hi].detach(), atol=1e-12)
+        for a, p in zip(dp_grads, params):
+            ok = ok and torch.allclose(a, p.grad, rtol=1e-10, atol=1e-12)
+        # mean convention (default divisor = world)
+        b2 = GradBucket(params, world)
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        b2.all_reduce_()
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2.0)) for p in params)
+        ok = ok and bucket.total == sum(p.numel() for p in params)
+        q.put((rank, bool(ok), bucket.total))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lowrank,ragged", [(False, False), (True, True)])
+def test_dp_two_ranks_matches_single_process(lowrank, ragged):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, lowrank, ragged, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    F, H = 5, 12
+    expect = (3 * (F + H) + 2 * 3 * H + 2 * H + 2) if lowrank else (H * F + H * H + 2 * H + 2)
+    assert res[0][2] == expect
+
+
+def test_shard_range_covers_everything():
+    from kws_amd.dp import shard_range
+    for n in (0, 1, 7, 8, 4096, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(32768, 3, 8) == (12288, 16384)
+
+
+def test_bucket_size_northstar():
+    """82 952 B dense (H=128,F=32) / 53 256 B low-rank (H=256,r=16): SURVEY.md section 8e."""
+    from kws_amd import FastGRNNCUDA
+    from kws_amd.dp import GradBucket
+    m = FastGRNNCUDA(32, 128, device="cpu")
+    assert GradBucket(list(m.parameters()), world=8).total * 4 == 82952
+    m = FastGRNNCUDA(32, 256, wRank=16, uRank=16, device="cpu")
+    assert GradBucket(list(m.parameters()), world=8).total * 4 == 53256

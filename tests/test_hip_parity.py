@@ -10,6 +10,8 @@ Tolerances (north_star: 1e-5 fp32 against the reference's CPU path):
     CPU result differs from its fp64 result by the same order (checked below).
   * fp64: 1e-12 / 1e-10.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -88,7 +90,7 @@ CASES = [
 @pytest.mark.parametrize("flags", [0, FORCE_GENERIC], ids=["dispatch", "generic"])
 def test_seeded_vs_oracle_fp32(case, flags):
     T, B, F, H, rw, ru, gate = case
-    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
     p = O.make_params(F, H, rw or None, ru or None, np.float32, seed=11, randomize_scalars=True)
     x = rng.standard_normal((T, B, F)).astype(np.float32)
     h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
@@ -98,8 +100,9 @@ def test_seeded_vs_oracle_fp32(case, flags):
     hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
     g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64,
                             h0.astype(np.float64), gate=gate)
-    assert np.abs(hs - hs_o).max() <= 1e-5
-    assert np.abs(zs - zs_o).max() <= 1e-5 and np.abs(cs - cs_o).max() <= 1e-5
+    # 1e-5 absolute while |h| <= 1, relative beyond (a tanh/relu gate does not bound h)
+    assert (np.abs(hs - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    assert (np.abs(zs - zs_o) / np.maximum(1.0, np.abs(zs_o))).max() <= 1e-5 and np.abs(cs - cs_o).max() <= 1e-5
     if gate == "relu":
         # a relu gate is discontinuous in its derivative: fp32-vs-fp64 sign flips of
         # pre-activations within 1e-6 of zero change d_pre by O(1); compare against the
