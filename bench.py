@@ -126,7 +126,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.fastgrnn_torch_port import time_fwd_bwd
-            cores = os.cpu_count() or 1
+            # the GPU box gives one GPU's job a 16-core CPU share; more threads than that
+            # only oversubscribes
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            cores = max(1, min(16, cores))
+            print("[bench] GPU leg done: %.0f utt/s; timing CPU baseline on %d threads ..." % (value, cores),
+                  file=sys.stderr, flush=True)
             r = time_fwd_bwd(B, T, F, H, threads=cores, budget_s=args.cpu_budget)
             out["cpu_baseline"] = {"value": r["utt_per_s"], "unit": "utterances/s", "cores": r["threads"],
                                    "kind": "port",
