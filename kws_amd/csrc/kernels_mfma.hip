@@ -127,18 +127,26 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
   for (int kk = 0; kk < KX; ++kk)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) accx[mt] = mfma4(Wf[mt][kk], xB[kk], accx[mt]);
+  // features of frame 1, carried across the loop back-edge: frame t+2 is requested at the
+  // top of step t and first read at the bottom of step t+1, one whole step later
+  f32x4 xv[KX / 4];
+  {
+    const float* xp = x + ((size_t)(Tn > 1 ? 1 : 0) * B + bc) * F + g * KX;
+#pragma unroll
+    for (int kq = 0; kq < KX / 4; ++kq) xv[kq] = ld4(xp + 4 * kq);
+  }
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < Tn; ++t) {
-    // prefetch the next frame's features (clamped at the last frame; unused there)
-    const int tn = (t + 1 < Tn) ? t + 1 : t;
-    f32x4 xv[KX / 4];
+    const int tn = (t + 2 < Tn) ? t + 2 : Tn - 1;      // clamped: the tail loads are unused
+    f32x4 xn[KX / 4];
     {
       const float* xp = x + ((size_t)tn * B + bc) * F + g * KX;
 #pragma unroll
-      for (int kq = 0; kq < KX / 4; ++kq) xv[kq] = ld4(xp + 4 * kq);
+      for (int kq = 0; kq < KX / 4; ++kq) xn[kq] = ld4(xp + 4 * kq);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // B operand: the whole state tile h_{t-1}
     float hB[KH];
 #pragma unroll
@@ -185,6 +193,8 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
         for (int mt = 0; mt < MT; ++mt) { st4(zs + o + 4 * mt, zv[mt]); st4(cs + o + 4 * mt, cv[mt]); }
       }
     }
+#pragma unroll
+    for (int kq = 0; kq < KX / 4; ++kq) xv[kq] = xn[kq];
     __syncthreads();
     cur ^= 1;
   }
@@ -193,6 +203,9 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
+// floats per workgroup slab of backward partial sums, padded to 64
+__host__ __device__ constexpr int slab_stride(int H, int F) { return (H * H + H * F + 2 * H + 2 + 63) & ~63; }
+
 template <int H, int F>
 struct BwdLds {
   static constexpr int HS = H / 4;
@@ -210,11 +223,7 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
     const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ d_x, float* __restrict__ d_h0,
-    float* __restrict__ part_w,    // [nwg][H*F]
-    float* __restrict__ part_u,    // [nwg][H*H]
-    float* __restrict__ part_bz,   // [nwg][H]
-    float* __restrict__ part_bh,   // [nwg][H]
-    float* __restrict__ part_zn)   // [nwg][2]
+    float* __restrict__ part)      // [nwg][slab_stride(H,F)]: dU | dW | d_bz | d_bh | (d_zeta, d_nu) sums
 {
   constexpr int HS = H / 4, MT = HS / 16, KH = H / 4, NQ = H / 16;
   constexpr int NCT = H / 16;      // column tiles of dU
@@ -270,28 +279,38 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
   float pz = 0.f, pn = 0.f;
   f32x4 dx_keep = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int t = Tn - 1; t >= 0; --t) {
-    const int buf = t & 1;
-    // ---- loads ---------------------------------------------------------------------------
+  // Operands of step t are requested during step t+1 (loop-carried registers), so a whole
+  // step of MFMA work covers the HBM latency.
+  f32x4 gv[MT], zv[MT], cv[MT], hp[MT];
+  float xT[NFT][4];
+  auto load_step = [&](int t, f32x4 (&gq)[MT], f32x4 (&zq)[MT], f32x4 (&cq)[MT], f32x4 (&hq)[MT],
+                       float (&xq)[NFT][4]) {
     const size_t o = ((size_t)t * B + bc) * H + n0;
-    f32x4 gv[MT], zv[MT], cv[MT], hp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      gv[mt] = ld4(ghs + o + 4 * mt);
-      zv[mt] = ld4(zs + o + 4 * mt);
-      cv[mt] = ld4(cs + o + 4 * mt);
-      hp[mt] = (t == 0) ? ld4(h0 + (size_t)bc * H + n0 + 4 * mt) : ld4(hs + o - (size_t)B * H + 4 * mt);  // .cu:478-481
+      gq[mt] = ld4(ghs + o + 4 * mt);
+      zq[mt] = ld4(zs + o + 4 * mt);
+      cq[mt] = ld4(cs + o + 4 * mt);
+      hq[mt] = (t == 0) ? ld4(h0 + (size_t)bc * H + n0 + 4 * mt) : ld4(hs + o - (size_t)B * H + 4 * mt);  // .cu:478-481
     }
-    // x_t^T fragments for dW: B[k = utterance 4g+kk][j = feature ft2*16 + i]
-    float xT[NFT][4];
+    // x_t^T fragments for dW: B[k = utterance 4g+kk][j = feature f2*16 + i]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int bb = blockIdx.x * 16 + 4 * g + kk;
       const bool ok = bb < B;
       const float* xp = x + ((size_t)t * B + (ok ? bb : B - 1)) * F + i;
 #pragma unroll
-      for (int f2 = 0; f2 < NFT; ++f2) { float v = xp[16 * f2]; xT[f2][kk] = ok ? v : 0.0f; }
+      for (int f2 = 0; f2 < NFT; ++f2) { float v = xp[16 * f2]; xq[f2][kk] = ok ? v : 0.0f; }
     }
+  };
+  load_step(Tn - 1, gv, zv, cv, hp, xT);
+
+  for (int t = Tn - 1; t >= 0; --t) {
+    const int buf = t & 1;
+    f32x4 gn[MT], zn[MT], cn[MT], hn[MT];
+    float xn[NFT][4];
+    load_step(t > 0 ? t - 1 : 0, gn, zn, cn, hn, xn);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- elementwise (.cu:107-117) ---------------------------------------------------------
     f32x4 dp[MT];
 #pragma unroll
@@ -367,6 +386,12 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
     } else if (valid) {
       st4(d_x + ((size_t)t * B + b) * F + ft * 16 + 4 * g, accx);
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { gv[mt] = gn[mt]; zv[mt] = zn[mt]; cv[mt] = cn[mt]; hp[mt] = hn[mt]; }
+#pragma unroll
+    for (int f2 = 0; f2 < NFT; ++f2)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xT[f2][kk] = xn[f2][kk];
   }
   __syncthreads();
   if (NSPLIT > 1 && nh == 0) {       // d_x of t = 0
@@ -382,8 +407,8 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
   }
   // dU / dW slabs: D row 4g+r of tile a is n = wv*HS + a*16 + 4g + r; column = c*16 + i
   {
-    float* pu = part_u + (size_t)blockIdx.x * H * H;
-    float* pw = part_w + (size_t)blockIdx.x * H * F;
+    float* pu = part + (size_t)blockIdx.x * slab_stride(H, F);
+    float* pw = pu + H * H;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -404,8 +429,9 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
       if (i == 0) {
-        part_bz[(size_t)blockIdx.x * H + n0 + 4 * mt + r] = a;
-        part_bh[(size_t)blockIdx.x * H + n0 + 4 * mt + r] = c;
+        float* pb = part + (size_t)blockIdx.x * slab_stride(H, F) + H * H + H * F;
+        pb[n0 + 4 * mt + r] = a;
+        pb[H + n0 + 4 * mt + r] = c;
       }
     }
 #pragma unroll
@@ -413,48 +439,57 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
   if (l == 0) { S.red[wv] = pz; S.red[4 + wv] = pn; }
   __syncthreads();
   if (tid == 0) {
-    part_zn[2 * blockIdx.x] = S.red[0] + S.red[1] + S.red[2] + S.red[3];
-    part_zn[2 * blockIdx.x + 1] = S.red[4] + S.red[5] + S.red[6] + S.red[7];
+    float* pzn = part + (size_t)blockIdx.x * slab_stride(H, F) + H * H + H * F + 2 * H;
+    pzn[0] = S.red[0] + S.red[1] + S.red[2] + S.red[3];
+    pzn[1] = S.red[4] + S.red[5] + S.red[6] + S.red[7];
   }
 }
 
-// Deterministic reduction of the per-workgroup slabs: out[i] = sum_wg part[wg][i].
-__global__ void reduce_slabs(int nwg, size_t n, const float* __restrict__ part, float* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int wg = 0;
-  for (; wg + 3 < nwg; wg += 4) {
-    a0 += part[(size_t)wg * n + i]; a1 += part[(size_t)(wg + 1) * n + i];
-    a2 += part[(size_t)(wg + 2) * n + i]; a3 += part[(size_t)(wg + 3) * n + i];
+// Deterministic reduction of the per-workgroup slabs in ONE launch: out[i] = sum_wg part[wg][i]
+// for the whole gradient vector dU | dW | d_bz | d_bh | d_zeta | d_nu (.cu:542-545).  A block
+// owns 64 consecutive outputs; its 1024 threads split the workgroups 16 ways (all loads of a
+// thread in flight at once), then 64 threads add the 16 partials in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_slabs(int nwg, int H, int F, int stride,
+                                                     const float* __restrict__ part,
+                                                     const float* __restrict__ zeta, const float* __restrict__ nu,
+                                                     float* __restrict__ d_u, float* __restrict__ d_w,
+                                                     float* __restrict__ d_bz, float* __restrict__ d_bh,
+                                                     float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, part_id = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
+  const int ntot = H * H + H * F + 2 * H + 2;
+  float a = 0.f;
+  if (idx < ntot) {
+    float v[8];
+    for (int wg0 = part_id; wg0 < nwg; wg0 += 16 * 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int wg = wg0 + 16 * j;
+        v[j] = wg < nwg ? part[(size_t)wg * stride + idx] : 0.f;
+      }
+      a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
   }
-  for (; wg < nwg; ++wg) a0 += part[(size_t)wg * n + i];
-  out[i] = (a0 + a1) + (a2 + a3);
+  sm[part_id][o] = a;
+  __syncthreads();
+  if (part_id == 0 && idx < ntot) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    const int oW = H * H, oBz = oW + H * F, oBh = oBz + H, oZ = oBh + H;
+    if (idx < oW) d_u[idx] = t;
+    else if (idx < oBz) d_w[idx - oW] = t;
+    else if (idx < oBh) d_bz[idx - oBz] = t;
+    else if (idx < oZ) d_bh[idx - oBh] = t;
+    else if (idx == oZ) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
+    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                      // .cu:117,545
+  }
 }
 
-__global__ void finalize_scalars(int nwg, const float* __restrict__ part_zn, const float* __restrict__ zeta,
-                                 const float* __restrict__ nu, float* __restrict__ d_zeta,
-                                 float* __restrict__ d_nu) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float a = 0.f, b = 0.f;
-    for (int wgi = 0; wgi < nwg; ++wgi) { a += part_zn[2 * wgi]; b += part_zn[2 * wgi + 1]; }
-    const float sz = 1.0f / (1.0f + expf(-zeta[0])), sn = 1.0f / (1.0f + expf(-nu[0]));
-    d_zeta[0] = a * sz * (1.0f - sz);   // .cu:116,544
-    d_nu[0] = b * sn * (1.0f - sn);     // .cu:117,545
-  }
-}
-
-struct MfmaBwdWs { size_t part_w, part_u, part_bz, part_bh, part_zn, total; };
-MfmaBwdWs bwd_ws_layout(const fastgrnn_desc& d) {
+size_t bwd_ws_bytes(const fastgrnn_desc& d) {
   size_t nwg = (d.B + 15) / 16;
-  MfmaBwdWs L; size_t o = 0;
-  L.part_w = o; o += align256(nwg * d.H * d.F * 4);
-  L.part_u = o; o += align256(nwg * (size_t)d.H * d.H * 4);
-  L.part_bz = o; o += align256(nwg * d.H * 4);
-  L.part_bh = o; o += align256(nwg * d.H * 4);
-  L.part_zn = o; o += align256(nwg * 2 * 4);
-  L.total = o;
-  return L;
+  return align256(nwg * (size_t)slab_stride(d.H, d.F) * 4);
 }
 
 template <int H, int F>
@@ -477,35 +512,23 @@ int launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, 
 template <int H, int F>
 int launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
-  MfmaBwdWs L = bwd_ws_layout(d);
-  char* base = reinterpret_cast<char*>(ws);
-  float* part_w = (float*)(base + L.part_w);
-  float* part_u = (float*)(base + L.part_u);
-  float* part_bz = (float*)(base + L.part_bz);
-  float* part_bh = (float*)(base + L.part_bh);
-  float* part_zn = (float*)(base + L.part_zn);
+  float* part = reinterpret_cast<float*>(ws);
   const int nwg = (d.B + 15) / 16;
   dim3 grid(nwg), block(256);
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)ghs, (const float*)x, (const float*)hs,
                        (const float*)zs, (const float*)cs, (const float*)h0, (const float*)p.w, (const float*)p.u,
-                       (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part_w, part_u,
-                       part_bz, part_bh, part_zn);
+                       (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
   };
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: args(bwd_scan_mfma<H, F, FASTGRNN_NL_SIGMOID>); break;
     case FASTGRNN_NL_RELU: args(bwd_scan_mfma<H, F, FASTGRNN_NL_RELU>); break;
     default: args(bwd_scan_mfma<H, F, FASTGRNN_NL_TANH>); break;
   }
-  auto red = [&](const float* part, size_t n, void* out) {
-    hipLaunchKernelGGL(reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nwg, n, part, (float*)out);
-  };
-  red(part_u, (size_t)H * H, g.d_u);
-  red(part_w, (size_t)H * F, g.d_w);
-  red(part_bz, (size_t)H, g.d_bias_gate);
-  red(part_bh, (size_t)H, g.d_bias_update);
-  hipLaunchKernelGGL(finalize_scalars, dim3(1), dim3(64), 0, s, nwg, part_zn, (const float*)p.zeta,
-                     (const float*)p.nu, (float*)g.d_zeta, (float*)g.d_nu);
+  const int ntot = H * H + H * F + 2 * H + 2;
+  hipLaunchKernelGGL(reduce_slabs, dim3((ntot + 63) / 64), dim3(1024), 0, s, nwg, H, F, slab_stride(H, F), part,
+                     (const float*)p.zeta, (const float*)p.nu, (float*)g.d_u, (float*)g.d_w,
+                     (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
 
@@ -518,7 +541,7 @@ bool mfma_supported(const fastgrnn_desc& d, int /*direction*/) {
          d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH && shape_ok(d.H, d.F);
 }
 size_t mfma_forward_ws(const fastgrnn_desc&) { return 0; }
-size_t mfma_backward_ws(const fastgrnn_desc& d) { return bwd_ws_layout(d).total; }
+size_t mfma_backward_ws(const fastgrnn_desc& d) { return bwd_ws_bytes(d); }
 
 int mfma_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                  void* zs, void* cs, void*, hipStream_t s) {
