@@ -22,6 +22,7 @@
 //
 // Reference semantics: forward .cu:42-60 + .cu:367-413; backward .cu:91-119 + .cu:473-545.
 #include "common.h"
+#include <type_traits>
 
 namespace fastgrnn {
 namespace {
@@ -53,13 +54,54 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// SCHED_PIN(idx): scheduling-region boundary.  Measured: with these pins hipcc keeps the
+// load requests, the dependent MFMA chain and the VALU/MFMA overlap region in the order
+// written, which is 20-25 % faster than its free schedule.  DIAG bit 32 removes the pins
+// (A/B), bit 16 additionally reads s_memtime there (diagnostic build only).
+#ifdef FASTGRNN_DIAG_STAMPS
+__device__ unsigned long long g_diag[4][16];
+#define SCHED_PIN(idx)                                                                    \
+  if (DIAG & 16) {                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long now_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    dsum[idx] += now_ - dlast; dlast = now_;                                              \
+  } else if (!(DIAG & 32)) {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  }
+#else
+#define SCHED_PIN(idx) if (!(DIAG & 32)) { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() would also emit
+// s_waitcnt vmcnt(0) and drain every in-flight global load/store each step; here only this
+// wave's LDS traffic is waited for, so prefetches and stores stay in flight across steps.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int H, int F, int GATE>
+// Step anatomy (one barrier per step; everything else is one basic block so that the
+// scheduler can interleave freely):
+//   top     request x_{t+1}; read the state tile h_{t-1} from LDS; 2*KX/… W.x_t MFMAs (they do
+//           not depend on h, so they cover the LDS round trip)
+//   chain   MT x H/4 dependent MFMAs U.h_{t-1}; the global stores of step t-1 (hs, z, c) are
+//           issued here, spread under the chain instead of in a burst in front of the barrier
+//   tail    gate/candidate/update on the VALU, new state tile to LDS, barrier
+// GATES_OUT: also write z_s / c_s (the reference operator's outputs).  RAGGED: B % 16 != 0
+// (stores are lane-predicated; kept out of the full-tile build so it has no branches).
+// DIAG (tools/diag_scan.hip only; production instantiates 0): 1 = no global stores,
+// 2 = no per-step barrier, 4 = cheap epilogue, 8 = no recurrent-chain MFMAs, 16 = cycle
+// stamps.  Ablations for timing; their results are wrong by construction.
+template <int H, int F, int GATE, bool GATES_OUT, bool RAGGED, int DIAG = 0>
 __global__ __launch_bounds__(256) void fwd_scan_mfma(
     int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -77,7 +119,7 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
   const int tid = threadIdx.x;
   const int wv = tid >> 6, l = tid & 63, i = l & 15, g = l >> 4;
   const int b = blockIdx.x * 16 + i;
-  const bool valid = b < B;
+  const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;                 // clamped row for loads
   const int n0 = wv * HS + g * (4 * MT);            // first of this lane's 4*MT hidden units
 
@@ -109,46 +151,36 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
   }
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
 
-  // x fragment of frame 0, and W.x_0
-  float xB[KX];
-  {
-    const float* xp = x + (size_t)bc * F + g * KX;
+  struct Feat { f32x4 v[KX / 4]; };       // one frame's features for this lane
+  struct Gates { f32x4 z[MT], c[MT]; };   // z_t, c_t awaiting their store
+  auto load_x = [&](int t, Feat& q) __attribute__((always_inline)) {
+    const float* xp = x + ((size_t)t * B + bc) * F + g * KX;
 #pragma unroll
-    for (int kq = 0; kq < KX / 4; ++kq) {
-      f32x4 v = ld4(xp + 4 * kq);
+    for (int kq = 0; kq < KX / 4; ++kq) q.v[kq] = ld4(xp + 4 * kq);
+  };
+  auto store_step = [&](int t, const Gates& gt) __attribute__((always_inline)) {     // hown still holds h_t here
+    if (DIAG & 1) return;
+    if (valid) {
+      const size_t o = ((size_t)t * B + b) * H + n0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xB[4 * kq + r] = v[r];
+      for (int mt = 0; mt < MT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
+      if (GATES_OUT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
+      }
     }
-  }
-  f32x4 accx[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) accx[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kk = 0; kk < KX; ++kk)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) accx[mt] = mfma4(Wf[mt][kk], xB[kk], accx[mt]);
-  // features of frame 1, carried across the loop back-edge: frame t+2 is requested at the
-  // top of step t and first read at the bottom of step t+1, one whole step later
-  f32x4 xv[KX / 4];
-  {
-    const float* xp = x + ((size_t)(Tn > 1 ? 1 : 0) * B + bc) * F + g * KX;
-#pragma unroll
-    for (int kq = 0; kq < KX / 4; ++kq) xv[kq] = ld4(xp + 4 * kq);
-  }
-  __syncthreads();
+  };
 
-  int cur = 0;
-  for (int t = 0; t < Tn; ++t) {
-    const int tn = (t + 2 < Tn) ? t + 2 : Tn - 1;      // clamped: the tail loads are unused
-    f32x4 xn[KX / 4];
-    {
-      const float* xp = x + ((size_t)tn * B + bc) * F + g * KX;
-#pragma unroll
-      for (int kq = 0; kq < KX / 4; ++kq) xn[kq] = ld4(xp + 4 * kq);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // B operand: the whole state tile h_{t-1}
-    float hB[KH];
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  if (DIAG & 16) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory"); }
+#endif
+  // Two register sets alternate between consecutive steps (features, gates), so that no
+  // copy -- and hence no wait for a load -- sits at a step boundary.
+  auto step = [&](auto first_tag, int t, int cur, Feat& xuse, Feat& xload, Gates& gprev, Gates& gout) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    load_x(t + 1 < Tn ? t + 1 : t, xload);            // clamped: the tail load is unused
+    float hB[KH];                                      // B operand: the whole state tile h_{t-1}
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       f32x4 v = hl[cur][(4 * q + g) * 16 + i];
@@ -157,47 +189,73 @@ __global__ __launch_bounds__(256) void fwd_scan_mfma(
     }
     f32x4 acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = accx[mt];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(Uf[mt][kk], hB[kk], acc[mt]);   // .cu:368
-    // W.x_{t+1}: independent of h_t, issued behind the recurrent chain so that the
-    // epilogue's VALU work below overlaps it
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) accx[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < KX; ++kk)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) accx[mt] = mfma4(Wf[mt][kk], xv[kk >> 2][kk & 3], accx[mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(Wf[mt][kk], xuse.v[kk >> 2][kk & 3], acc[mt]);
+    SCHED_PIN(0)   // x request + LDS state read + W.x MFMAs issued
+    if (!FIRST) store_step(t - 1, gprev);
+    if (!(DIAG & 8)) {
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma4(Uf[mt][kk], hB[kk], acc[mt]);   // .cu:368
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) acc[kk % MT][kk & 3] += Uf[kk % MT][kk] * hB[kk];
+    }
+    if (!FIRST && !(DIAG & (1 | 8 | 64))) {
+      // spread the NST store instructions of step t-1 evenly under the MT*KH chain MFMAs
+      constexpr int NST = GATES_OUT ? 3 * MT : MT;
+      constexpr int PER = (MT * KH) / (NST + 1);
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);     // VMEM write
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * KH - NST * PER, 0);
+    }
+    SCHED_PIN(1)   // stores of step t-1 + recurrent chain issued
     // epilogue (.cu:55-58)
-    f32x4 zv[MT], cv[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pre = acc[mt][r];
-        const float z = gate_act<GATE>(pre + bzv[mt][r]);
-        const float c = ftanh(pre + bhv[mt][r]);
+        const float z = (DIAG & 4) ? pre * bzv[mt][r] : gate_act<GATE>(pre + bzv[mt][r]);
+        const float c = (DIAG & 4) ? pre * bhv[mt][r] : ftanh(pre + bhv[mt][r]);
         hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
-        zv[mt][r] = z; cv[mt][r] = c;
+        gout.z[mt][r] = z; gout.c[mt][r] = c;
       }
       hl[cur ^ 1][(wv * (HS / 4) + g * MT + mt) * 16 + i] = hown[mt];
     }
-    if (valid) {
-      const size_t o = ((size_t)t * B + b) * H + n0;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
-      if (zs) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { st4(zs + o + 4 * mt, zv[mt]); st4(cs + o + 4 * mt, cv[mt]); }
-      }
-    }
-#pragma unroll
-    for (int kq = 0; kq < KX / 4; ++kq) xv[kq] = xn[kq];
-    __syncthreads();
-    cur ^= 1;
+    SCHED_PIN(2)   // epilogue + LDS write issued
+    if (!(DIAG & 2)) lds_barrier();
+    SCHED_PIN(3)   // barrier passed
+  };
+
+  Feat xa, xb;
+  Gates ga, gb;
+  load_x(0, xa);
+  __syncthreads();
+  step(std::true_type{}, 0, 0, xa, xb, gb, ga);
+  int t = 1;
+  for (; t + 1 < Tn; t += 2) {
+    step(std::false_type{}, t, 1, xb, xa, ga, gb);
+    step(std::false_type{}, t + 1, 0, xa, xb, gb, ga);
   }
+  if (t < Tn) {                       // Tn even: one more step, parity 1
+    step(std::false_type{}, t, 1, xb, xa, ga, gb);
+    store_step(Tn - 1, gb);
+  } else {
+    store_step(Tn - 1, ga);
+  }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if ((DIAG & 16) && blockIdx.x == 7 && l == 0) {
+    for (int k = 0; k < 8; ++k) g_diag[wv][k] = dsum[k];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -212,11 +270,19 @@ struct BwdLds {
   f32x4 P[2][(H / 4) * 16];          // d_pre tile, [n/4][b] float4   (B operand of d_h, d_x)
   float Tt[2][4][HS][20];            // d_pre^T per wave, [n_local][b] (A operand of dW, dU)
   float Hp[2][16][H + 4];            // h_prev tile, [b][k]            (B operand of dU)
-  f32x4 DX[2][3][64];                // d_x partial sums from the waves that split K
+  f32x4 DX[2][4][F / 16][64];        // d_x partial sums of every wave, per feature tile
   float red[8];
 };
 
-template <int H, int F, int GATE>
+// Reverse scan, software-pipelined over two steps.  Per step t and per wave:
+//   MM(t)  64 dependent MFMAs  d_h = z*g + U^T d_pre_t          (the serial chain)
+//          96 independent MFMAs d_x partial, dW += d_pre_t^T x_t, dU += d_pre_t^T h_{t-1}
+//   EW(t)  gate/candidate derivatives on the VALU -> d_pre_t, published through LDS
+// Iteration t runs [chain(t)] then [off-chain MM(t) || EW(t-1)] in ONE basic block, so the
+// matrix pipe works on the 96 independent MFMAs while the VALU prepares the next step's
+// d_pre; one raw s_barrier per step.  Global operands are requested one iteration before
+// their use into alternating register sets (no copies, no early waits).
+template <int H, int F, int GATE, bool RAGGED, int DIAG = 0>
 __global__ __launch_bounds__(256) void bwd_scan_mfma(
     int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ zs, const float* __restrict__ cs,
@@ -228,18 +294,17 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
   constexpr int HS = H / 4, MT = HS / 16, KH = H / 4, NQ = H / 16;
   constexpr int NCT = H / 16;      // column tiles of dU
   constexpr int NFT = F / 16;      // feature tiles (d_x rows, dW columns)
-  constexpr int NSPLIT = 4 / NFT;  // waves that split the K (=n) range of one d_x tile
-  constexpr int KD = KH / NSPLIT;  // MFMA steps of d_x per wave
-  static_assert(NFT == 1 || NFT == 2 || NFT == 4, "F must be 16, 32 or 64");
+  constexpr int KD = 4 * MT;       // MFMA steps of this wave's d_x partial (K = its own hidden slice)
+  static_assert(NFT >= 1 && NFT <= 4, "F must be 16..64");
   __shared__ BwdLds<H, F> S;
 
   const int tid = threadIdx.x;
-  const int wv = tid >> 6, l = tid & 63, i = l & 15, g = l >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
   const int b = blockIdx.x * 16 + i;
-  const bool valid = b < B;
+  const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
   const int n0 = wv * HS + g * (4 * MT);
-  const int ft = wv % NFT, nh = wv / NFT;           // d_x role of this wave
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
 
   // ---- resident A operands -----------------------------------------------------------------
@@ -254,14 +319,14 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
       UTf[mt][kk] = u[(size_t)n * H + kA];
     }
   }
-  // d_x[f][b] = sum_n W[n][f] d_pre[b][n]:  tile ft, K range [nh*KD, nh*KD+KD)
-  float WTf[KD];
+  // d_x[f][b] = sum_n W[n][f] d_pre[b][n]: every wave contracts over ITS OWN hidden slice, with
+  // the B operand taken straight from its d_pre registers (MFMA step 4mt+r <-> n = n0+4mt+r);
+  // the four partial sums meet in LDS.
+  float WTf[NFT][KD];
 #pragma unroll
-  for (int kk = 0; kk < KD; ++kk) {
-    const int k2 = nh * KD + kk;
-    const int n = 16 * (k2 >> 2) + 4 * g + (k2 & 3);
-    WTf[kk] = w[(size_t)n * F + ft * 16 + i];
-  }
+  for (int f2 = 0; f2 < NFT; ++f2)
+#pragma unroll
+    for (int kk = 0; kk < KD; ++kk) WTf[f2][kk] = w[(size_t)(n0 + kk) * F + f2 * 16 + i];
 
   f32x4 accU[MT][NCT], accW[MT][NFT];
 #pragma unroll
@@ -277,129 +342,160 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
     sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt];
   }
   float pz = 0.f, pn = 0.f;
-  f32x4 dx_keep = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Operands of step t are requested during step t+1 (loop-carried registers), so a whole
-  // step of MFMA work covers the HBM latency.
-  f32x4 gv[MT], zv[MT], cv[MT], hp[MT];
-  float xT[NFT][4];
-  auto load_step = [&](int t, f32x4 (&gq)[MT], f32x4 (&zq)[MT], f32x4 (&cq)[MT], f32x4 (&hq)[MT],
-                       float (&xq)[NFT][4]) {
+  struct EwOps { f32x4 g[MT], z[MT], c[MT], h[MT]; };   // operands of EW(t)
+  struct XT { float v[NFT][4]; };                        // x_t^T fragments for dW
+  auto load_ew = [&](int t, EwOps& q) __attribute__((always_inline)) {
     const size_t o = ((size_t)t * B + bc) * H + n0;
+    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)B * H;   // .cu:478-481
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      gq[mt] = ld4(ghs + o + 4 * mt);
-      zq[mt] = ld4(zs + o + 4 * mt);
-      cq[mt] = ld4(cs + o + 4 * mt);
-      hq[mt] = (t == 0) ? ld4(h0 + (size_t)bc * H + n0 + 4 * mt) : ld4(hs + o - (size_t)B * H + 4 * mt);  // .cu:478-481
+      q.g[mt] = ld4(ghs + o + 4 * mt);
+      q.z[mt] = ld4(zs + o + 4 * mt);
+      q.c[mt] = ld4(cs + o + 4 * mt);
+      q.h[mt] = ld4(hprev + 4 * mt);
     }
-    // x_t^T fragments for dW: B[k = utterance 4g+kk][j = feature f2*16 + i]
+  };
+  auto load_xt = [&](int t, XT& q) __attribute__((always_inline)) {   // B[k = utterance 4g+kk][j = feature f2*16 + i]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int bb = blockIdx.x * 16 + 4 * g + kk;
-      const bool ok = bb < B;
-      const float* xp = x + ((size_t)t * B + (ok ? bb : B - 1)) * F + i;
+      const float* xp = x + ((size_t)t * B + ((!RAGGED || bb < B) ? bb : B - 1)) * F + i;
 #pragma unroll
-      for (int f2 = 0; f2 < NFT; ++f2) { float v = xp[16 * f2]; xq[f2][kk] = ok ? v : 0.0f; }
+      for (int f2 = 0; f2 < NFT; ++f2) q.v[f2][kk] = xp[16 * f2];   // rows past B multiply d_pre = 0
     }
   };
-  load_step(Tn - 1, gv, zv, cv, hp, xT);
 
-  for (int t = Tn - 1; t >= 0; --t) {
+  // EW(t): .cu:107-117.  Consumes dh = d_old_h from chain(t+1); leaves dh = z*g (the C-in of
+  // chain(t)) and publishes d_pre_t / h_{t-1} in LDS buffers [t&1].
+  auto ew = [&](int t, const EwOps& q) __attribute__((always_inline)) {
     const int buf = t & 1;
-    f32x4 gn[MT], zn[MT], cn[MT], hn[MT];
-    float xn[NFT][4];
-    load_step(t > 0 ? t - 1 : 0, gn, zn, cn, hn, xn);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- elementwise (.cu:107-117) ---------------------------------------------------------
-    f32x4 dp[MT];
+    f32x4 dpo[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      f32x4 hpv = q.h[mt], dpv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float gg = gv[mt][r] + dh[mt][r];                                  // .cu:474
-        const float z = zv[mt][r], c = cv[mt][r];
+        const float gg = q.g[mt][r] + dh[mt][r];                                 // .cu:474
+        const float z = q.z[mt][r], c = q.c[mt][r];
         float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
-        float dzp = (hp[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;              // .cu:110
+        float dzp = (hpv[r] - sz * c) * gate_dact<GATE>(z) * gg;                 // .cu:110
         float zg = z * gg;                                                        // .cu:108
         float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
-        if (!valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; }
+        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hpv[r] = 0.f; }
         sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
-        dp[mt][r] = dzp + dcp;                                                    // .cu:113
+        dpv[r] = dzp + dcp;                                                       // .cu:113
         dh[mt][r] = zg;
-        if (!valid) hp[mt][r] = 0.f;
       }
-      S.P[buf][(wv * (HS / 4) + g * MT + mt) * 16 + i] = dp[mt];
-      *reinterpret_cast<f32x4*>(&S.Hp[buf][i][n0 + 4 * mt]) = hp[mt];
+      S.P[buf][(wv * (HS / 4) + g * MT + mt) * 16 + i] = dpv;
+      *reinterpret_cast<f32x4*>(&S.Hp[buf][i][n0 + 4 * mt]) = hpv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S.Tt[buf][wv][g * (4 * MT) + mt * 4 + r][i] = dp[mt][r];
+      for (int r = 0; r < 4; ++r) S.Tt[buf][wv][g * (4 * MT) + mt * 4 + r][i] = dpv[r];
+      dpo[mt] = dpv;
     }
-    __syncthreads();
-    // ---- finish d_x of the PREVIOUS step (its partial sums were published before this barrier)
-    if (NSPLIT > 1 && nh == 0 && t + 1 < Tn) {
-      f32x4 s = dx_keep;
+    // d_x partial over this wave's hidden slice (.cu:538)
 #pragma unroll
-      for (int k = 1; k < NSPLIT; ++k) s += S.DX[buf ^ 1][(k - 1) * NFT + ft][l];
-      if (valid) st4(d_x + ((size_t)(t + 1) * B + b) * F + ft * 16 + 4 * g, s);
+    for (int f2 = 0; f2 < NFT; ++f2) {
+      f32x4 accx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accx = mfma4(WTf[f2][4 * mt + r], dpo[mt][r], accx);
+      S.DX[buf][wv][f2][l] = accx;
     }
+  };
+
+  // d_x of step t = sum of the four waves' partials (published by EW(t) before the barrier);
+  // wave f2 < NFT finishes feature tile f2.
+  auto finish_dx = [&](int t) __attribute__((always_inline)) {
+    if (wv < NFT) {                         // wave-uniform (wv is an SGPR)
+      f32x4 sacc = (S.DX[t & 1][0][wv][l] + S.DX[t & 1][1][wv][l]) + (S.DX[t & 1][2][wv][l] + S.DX[t & 1][3][wv][l]);
+      if (valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, sacc);
+    }
+  };
+
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  if (DIAG & 16) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory"); }
+#endif
+
+  // One pipelined iteration: MM(t) and, unless LAST, EW(t-1) + the operand requests for the
+  // iteration after.
+  auto iter = [&](auto last_tag, int t) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int buf = t & 1;
     // ---- operands from LDS ------------------------------------------------------------------
     float dpB[KH];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      f32x4 v = S.P[buf][(4 * q + g) * 16 + i];
+    for (int qq = 0; qq < NQ; ++qq) {
+      f32x4 v = S.P[buf][(4 * qq + g) * 16 + i];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dpB[4 * q + r] = v[r];
+      for (int r = 0; r < 4; ++r) dpB[4 * qq + r] = v[r];
     }
     f32x4 dpT[MT];
 #pragma unroll
-    for (int a = 0; a < MT; ++a) dpT[a] = *reinterpret_cast<const f32x4*>(&S.Tt[buf][wv][a * 16 + i][4 * g]);
+    for (int a2 = 0; a2 < MT; ++a2) dpT[a2] = *reinterpret_cast<const f32x4*>(&S.Tt[buf][wv][a2 * 16 + i][4 * g]);
+    SCHED_PIN(0)   // LDS reads
+    // Operands of EW(t-1) and of dW(t) are requested here and first read after the chain,
+    // ~2200 MFMA cycles later (one register set; a second set does not fit in 256 VGPRs).
+    // The requests are issued in the shadow of the chain's MFMAs, not in front of them.
+    EwOps eo;
+    XT xo;
+    if (!LAST) load_ew(t - 1, eo);
+    load_xt(t, xo);
     // ---- d_h chain (.cu:537): C-in = z*g --------------------------------------------------
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma4(UTf[mt][kk], dpB[kk], dh[mt]);
-    // ---- d_x partial (.cu:538) -------------------------------------------------------------
-    f32x4 accx = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(DIAG & 64)) {
+      constexpr int NLD = (LAST ? 0 : 4 * MT) + 4 * NFT;       // load instructions in this region
+      constexpr int PER = (MT * KH) / (NLD + 1) > 0 ? (MT * KH) / (NLD + 1) : 1;
 #pragma unroll
-    for (int kk = 0; kk < KD; ++kk) accx = mfma4(WTf[kk], dpB[nh * KD + kk], accx);
+      for (int j = 0; j < NLD; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
+    }
+    SCHED_PIN(1)   // chain issued
+    finish_dx(t);                          // its partials were published before the last barrier
     // ---- dW (.cu:539), dU (.cu:540): K = the 16 utterances ---------------------------------
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+      for (int a2 = 0; a2 < MT; ++a2)
 #pragma unroll
-        for (int f2 = 0; f2 < NFT; ++f2) accW[a][f2] = mfma4(dpT[a][kk], xT[f2][kk], accW[a][f2]);
+        for (int f2 = 0; f2 < NFT; ++f2) accW[a2][f2] = mfma4(dpT[a2][kk], xo.v[f2][kk], accW[a2][f2]);
     }
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
+    for (int c2 = 0; c2 < NCT; ++c2) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const float hv = S.Hp[buf][4 * g + kk][c * 16 + i];
+        const float hv = S.Hp[buf][4 * g + kk][c2 * 16 + i];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) accU[a][c] = mfma4(dpT[a][kk], hv, accU[a][c]);
+        for (int a2 = 0; a2 < MT; ++a2) accU[a2][c2] = mfma4(dpT[a2][kk], hv, accU[a2][c2]);
       }
     }
-    // publish / keep the d_x partial of this step
-    if (NSPLIT > 1) {
-      if (nh == 0) dx_keep = accx;
-      else S.DX[buf][(nh - 1) * NFT + ft][l] = accx;
-    } else if (valid) {
-      st4(d_x + ((size_t)t * B + b) * F + ft * 16 + 4 * g, accx);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { gv[mt] = gn[mt]; zv[mt] = zn[mt]; cv[mt] = cn[mt]; hp[mt] = hn[mt]; }
-#pragma unroll
-    for (int f2 = 0; f2 < NFT; ++f2)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xT[f2][kk] = xn[f2][kk];
+    // ---- EW(t-1): overlaps the independent MFMAs above ---------------------------------------
+    if (!LAST) ew(t - 1, eo);
+    SCHED_PIN(2)   // off-chain MFMAs + EW(t-1) + LDS writes issued
+    lds_barrier();
+    SCHED_PIN(3)   // barrier passed
+  };
+
+  {
+    EwOps e0;
+    load_ew(Tn - 1, e0);
+    ew(Tn - 1, e0);
   }
-  __syncthreads();
-  if (NSPLIT > 1 && nh == 0) {       // d_x of t = 0
-    f32x4 s = dx_keep;
-#pragma unroll
-    for (int k = 1; k < NSPLIT; ++k) s += S.DX[0][(k - 1) * NFT + ft][l];
-    if (valid) st4(d_x + (size_t)b * F + ft * 16 + 4 * g, s);
+  lds_barrier();
+  for (int t = Tn - 1; t >= 1; --t) iter(std::false_type{}, t);
+  iter(std::true_type{}, 0);
+#ifdef FASTGRNN_DIAG_STAMPS
+  if ((DIAG & 16) && blockIdx.x == 7 && l == 0) {
+    for (int k = 0; k < 8; ++k) g_diag[wv][k] = dsum[k];
   }
+#endif
   // ---- flush ---------------------------------------------------------------------------------
   if (valid) {
 #pragma unroll
@@ -496,15 +592,21 @@ template <int H, int F>
 int launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
                void* cs, hipStream_t s) {
   dim3 grid((d.B + 15) / 16), block(256);
-  auto args = [&](auto kern) {
+  auto args = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  const bool ragged = (d.B % 16) != 0, gates = zs != nullptr;
+  auto pick = [&](auto gate_c) __attribute__((always_inline)) {
+    constexpr int G = decltype(gate_c)::value;
+    if (gates) { if (ragged) args(fwd_scan_mfma<H, F, G, true, true>); else args(fwd_scan_mfma<H, F, G, true, false>); }
+    else       { if (ragged) args(fwd_scan_mfma<H, F, G, false, true>); else args(fwd_scan_mfma<H, F, G, false, false>); }
+  };
   switch (d.gate_nl) {
-    case FASTGRNN_NL_SIGMOID: args(fwd_scan_mfma<H, F, FASTGRNN_NL_SIGMOID>); break;
-    case FASTGRNN_NL_RELU: args(fwd_scan_mfma<H, F, FASTGRNN_NL_RELU>); break;
-    default: args(fwd_scan_mfma<H, F, FASTGRNN_NL_TANH>); break;
+    case FASTGRNN_NL_SIGMOID: pick(std::integral_constant<int, FASTGRNN_NL_SIGMOID>{}); break;
+    case FASTGRNN_NL_RELU: pick(std::integral_constant<int, FASTGRNN_NL_RELU>{}); break;
+    default: pick(std::integral_constant<int, FASTGRNN_NL_TANH>{}); break;
   }
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
@@ -515,15 +617,20 @@ int launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs
   float* part = reinterpret_cast<float*>(ws);
   const int nwg = (d.B + 15) / 16;
   dim3 grid(nwg), block(256);
-  auto args = [&](auto kern) {
+  auto args = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)ghs, (const float*)x, (const float*)hs,
                        (const float*)zs, (const float*)cs, (const float*)h0, (const float*)p.w, (const float*)p.u,
                        (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
   };
+  const bool ragged = (d.B % 16) != 0;
+  auto pick = [&](auto gate_c) __attribute__((always_inline)) {
+    constexpr int G = decltype(gate_c)::value;
+    if (ragged) args(bwd_scan_mfma<H, F, G, true>); else args(bwd_scan_mfma<H, F, G, false>);
+  };
   switch (d.gate_nl) {
-    case FASTGRNN_NL_SIGMOID: args(bwd_scan_mfma<H, F, FASTGRNN_NL_SIGMOID>); break;
-    case FASTGRNN_NL_RELU: args(bwd_scan_mfma<H, F, FASTGRNN_NL_RELU>); break;
-    default: args(bwd_scan_mfma<H, F, FASTGRNN_NL_TANH>); break;
+    case FASTGRNN_NL_SIGMOID: pick(std::integral_constant<int, FASTGRNN_NL_SIGMOID>{}); break;
+    case FASTGRNN_NL_RELU: pick(std::integral_constant<int, FASTGRNN_NL_RELU>{}); break;
+    default: pick(std::integral_constant<int, FASTGRNN_NL_TANH>{}); break;
   }
   const int ntot = H * H + H * F + 2 * H + 2;
   hipLaunchKernelGGL(reduce_slabs, dim3((ntot + 63) / 64), dim3(1024), 0, s, nwg, H, F, slab_stride(H, F), part,
