@@ -356,57 +356,74 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
       q.h[mt] = ld4(hprev + 4 * mt);
     }
   };
-  auto load_xt = [&](int t, XT& q) __attribute__((always_inline)) {   // B[k = utterance 4g+kk][j = feature f2*16 + i]
+  auto load_xt = [&](int t, XT& q) __attribute__((always_inline)) {   // B[k = utterance 4g+kk][j = i]: feature i*NFT + f2
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int bb = blockIdx.x * 16 + 4 * g + kk;
-      const float* xp = x + ((size_t)t * B + ((!RAGGED || bb < B) ? bb : B - 1)) * F + i;
+      const float* xp = x + ((size_t)t * B + ((!RAGGED || bb < B) ? bb : B - 1)) * F + i * NFT;
+      if (NFT == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(xp);        // rows past B multiply d_pre = 0
+        q.v[0][kk] = v.x; q.v[1][kk] = v.y;
+      } else if (NFT == 4) {
+        const f32x4 v = ld4(xp);
 #pragma unroll
-      for (int f2 = 0; f2 < NFT; ++f2) q.v[f2][kk] = xp[16 * f2];   // rows past B multiply d_pre = 0
+        for (int f2 = 0; f2 < NFT; ++f2) q.v[f2][kk] = v[f2];
+      } else {
+#pragma unroll
+        for (int f2 = 0; f2 < NFT; ++f2) q.v[f2][kk] = xp[f2];
+      }
     }
   };
 
-  // EW(t): .cu:107-117.  Consumes dh = d_old_h from chain(t+1); leaves dh = z*g (the C-in of
-  // chain(t)) and publishes d_pre_t / h_{t-1} in LDS buffers [t&1].
-  auto ew = [&](int t, const EwOps& q) __attribute__((always_inline)) {
+  // EW(t): .cu:107-117, in NR = 4 chunks of MT elements so that each chunk can share a pinned
+  // scheduling region with a batch of independent MFMAs.  Consumes dh = d_old_h from
+  // chain(t+1) and leaves dh = z*g, the C-in of chain(t).
+  struct EwOut { f32x4 dp[MT], hp[MT]; };
+  auto ew_chunk = [&](int j, const EwOps& q, EwOut& o) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      const int e = j * MT + k, mt = e >> 2, r = e & 3;
+      const float gg = q.g[mt][r] + dh[mt][r];                                   // .cu:474
+      const float z = q.z[mt][r], c = q.c[mt][r];
+      float hv = q.h[mt][r];
+      float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                  // .cu:109
+      float dzp = (hv - sz * c) * gate_dact<GATE>(z) * gg;                       // .cu:110
+      float zg = z * gg;                                                          // .cu:108
+      float tz = (1.0f - z) * c * gg, tn = c * gg;                                // .cu:114-115
+      if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hv = 0.f; }
+      sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
+      o.dp[mt][r] = dzp + dcp;                                                    // .cu:113
+      o.hp[mt][r] = hv;
+      dh[mt][r] = zg;
+    }
+  };
+  // publish d_pre_t / h_{t-1} in LDS buffers [t&1]; keep d_pre_t in registers for d_x
+  auto ew_publish = [&](int t, const EwOut& o, f32x4 (&dpo)[MT]) __attribute__((always_inline)) {
     const int buf = t & 1;
-    f32x4 dpo[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      f32x4 hpv = q.h[mt], dpv;
+      S.P[buf][(wv * (HS / 4) + g * MT + mt) * 16 + i] = o.dp[mt];
+      *reinterpret_cast<f32x4*>(&S.Hp[buf][i][n0 + 4 * mt]) = o.hp[mt];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gg = q.g[mt][r] + dh[mt][r];                                 // .cu:474
-        const float z = q.z[mt][r], c = q.c[mt][r];
-        float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
-        float dzp = (hpv[r] - sz * c) * gate_dact<GATE>(z) * gg;                 // .cu:110
-        float zg = z * gg;                                                        // .cu:108
-        float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
-        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hpv[r] = 0.f; }
-        sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
-        dpv[r] = dzp + dcp;                                                       // .cu:113
-        dh[mt][r] = zg;
-      }
-      S.P[buf][(wv * (HS / 4) + g * MT + mt) * 16 + i] = dpv;
-      *reinterpret_cast<f32x4*>(&S.Hp[buf][i][n0 + 4 * mt]) = hpv;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S.Tt[buf][wv][g * (4 * MT) + mt * 4 + r][i] = dpv[r];
-      dpo[mt] = dpv;
-    }
-    // d_x partial over this wave's hidden slice (.cu:538)
-#pragma unroll
-    for (int f2 = 0; f2 < NFT; ++f2) {
-      f32x4 accx = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) accx = mfma4(WTf[f2][4 * mt + r], dpo[mt][r], accx);
-      S.DX[buf][wv][f2][l] = accx;
+      for (int r = 0; r < 4; ++r) S.Tt[buf][wv][g * (4 * MT) + mt * 4 + r][i] = o.dp[mt][r];
+      dpo[mt] = o.dp[mt];
     }
   };
-
-  // d_x of step t = sum of the four waves' partials (published by EW(t) before the barrier);
-  // wave f2 < NFT finishes feature tile f2.
+  // d_x partial of step t over this wave's hidden slice (.cu:538): register operands only
+  auto dx_partial = [&](int t, const f32x4 (&dpo)[MT]) __attribute__((always_inline)) {
+    f32x4 accx[NFT];
+#pragma unroll
+    for (int f2 = 0; f2 < NFT; ++f2) accx[f2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int f2 = 0; f2 < NFT; ++f2) accx[f2] = mfma4(WTf[f2][4 * mt + r], dpo[mt][r], accx[f2]);
+#pragma unroll
+    for (int f2 = 0; f2 < NFT; ++f2) S.DX[t & 1][wv][f2][l] = accx[f2];
+  };
+  // d_x of step t = sum of the four waves' partials; wave f2 < NFT finishes feature tile f2.
   auto finish_dx = [&](int t) __attribute__((always_inline)) {
     if (wv < NFT) {                         // wave-uniform (wv is an SGPR)
       f32x4 sacc = (S.DX[t & 1][0][wv][l] + S.DX[t & 1][1][wv][l]) + (S.DX[t & 1][2][wv][l] + S.DX[t & 1][3][wv][l]);
@@ -419,9 +436,14 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
   if (DIAG & 16) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory"); }
 #endif
 
-  // One pipelined iteration: MM(t) and, unless LAST, EW(t-1) + the operand requests for the
-  // iteration after.
-  auto iter = [&](auto last_tag, int t) __attribute__((always_inline)) {
+  // One pipelined iteration.  dpo holds d_pre_{t+1} on entry (B operand of d_x(t+1)) and
+  // receives d_pre_{t-1} at the end.
+  //   top    LDS reads for chain(t); the 8*NFT register-only d_x(t+1) MFMAs cover their latency
+  //   chain  64 dependent MFMAs; the global operand requests are issued in their shadow
+  //   4 x    { dW/dU MFMAs of step t  ||  one chunk of EW(t-1) }   (pinned regions)
+  //   end    publish d_pre_{t-1}; barrier
+  auto iter = [&](auto last_tag, int t, f32x4 (&dpo)[MT], const EwOps& eo, EwOps& e_load, const XT& xo,
+                  XT& x_load) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;
     const int buf = t & 1;
     // ---- operands from LDS ------------------------------------------------------------------
@@ -435,21 +457,21 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
     f32x4 dpT[MT];
 #pragma unroll
     for (int a2 = 0; a2 < MT; ++a2) dpT[a2] = *reinterpret_cast<const f32x4*>(&S.Tt[buf][wv][a2 * 16 + i][4 * g]);
-    SCHED_PIN(0)   // LDS reads
-    // Operands of EW(t-1) and of dW(t) are requested here and first read after the chain,
-    // ~2200 MFMA cycles later (one register set; a second set does not fit in 256 VGPRs).
-    // The requests are issued in the shadow of the chain's MFMAs, not in front of them.
-    EwOps eo;
-    XT xo;
-    if (!LAST) load_ew(t - 1, eo);
-    load_xt(t, xo);
+    if (t + 1 < Tn) dx_partial(t + 1, dpo);
+    SCHED_PIN(0)   // LDS reads + d_x(t+1) MFMAs
+    // Operands of EW(t-2) and of dW(t-1) are requested here, a whole iteration before their
+    // use (eo / xo were requested during iteration t+1), into the alternate register set.
+    if (!LAST) {
+      load_xt(t - 1, x_load);
+      load_ew(t >= 2 ? t - 2 : 0, e_load);
+    }
     // ---- d_h chain (.cu:537): C-in = z*g --------------------------------------------------
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma4(UTf[mt][kk], dpB[kk], dh[mt]);
     if (!(DIAG & 64)) {
-      constexpr int NLD = (LAST ? 0 : 4 * MT) + 4 * NFT;       // load instructions in this region
+      constexpr int NLD = LAST ? 0 : 4 * MT + 4;               // load instructions in this region
       constexpr int PER = (MT * KH) / (NLD + 1) > 0 ? (MT * KH) / (NLD + 1) : 1;
 #pragma unroll
       for (int j = 0; j < NLD; ++j) {
@@ -458,39 +480,82 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
       }
     }
     SCHED_PIN(1)   // chain issued
-    finish_dx(t);                          // its partials were published before the last barrier
-    // ---- dW (.cu:539), dU (.cu:540): K = the 16 utterances ---------------------------------
+    if (t + 2 < Tn) finish_dx(t + 2);      // published at the top of the previous iteration
+    // ---- dW (.cu:539), dU (.cu:540) with K = the 16 utterances, overlapped with EW(t-1) --------
+    EwOut eo_out;
+    // Region j = MFMA K-step j (utterances 4g+j): B operands are row 4g+j of the h_prev tile,
+    // NCT contiguous floats per lane (dU column of tile c2, lane i is i*NCT + c2), read one
+    // region ahead so that no MFMA waits on LDS latency.
+    f32x4 hrow[2][NCT / 4];
+    auto read_hrow = [&](int j, f32x4 (&dst)[NCT / 4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+      for (int v = 0; v < NCT / 4; ++v) dst[v] = *reinterpret_cast<const f32x4*>(&S.Hp[buf][4 * g + j][i * NCT + 4 * v]);
+    };
+    read_hrow(0, hrow[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j + 1 < 4) read_hrow(j + 1, hrow[(j + 1) & 1]);
 #pragma unroll
       for (int a2 = 0; a2 < MT; ++a2)
 #pragma unroll
-        for (int f2 = 0; f2 < NFT; ++f2) accW[a2][f2] = mfma4(dpT[a2][kk], xo.v[f2][kk], accW[a2][f2]);
-    }
+        for (int f2 = 0; f2 < NFT; ++f2) accW[a2][f2] = mfma4(dpT[a2][j], xo.v[f2][j], accW[a2][f2]);
 #pragma unroll
-    for (int c2 = 0; c2 < NCT; ++c2) {
+      for (int c2 = 0; c2 < NCT; ++c2)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float hv = S.Hp[buf][4 * g + kk][c2 * 16 + i];
+        for (int a2 = 0; a2 < MT; ++a2) accU[a2][c2] = mfma4(dpT[a2][j], hrow[j & 1][c2 >> 2][c2 & 3], accU[a2][c2]);
+      if (!LAST) ew_chunk(j, eo, eo_out);
+      if (!LAST && !(DIAG & 128)) {
+        // fine interleave: the VALU work of the chunk goes between the independent MFMAs
+        constexpr int NM = MT * NFT + MT * NCT;
 #pragma unroll
-        for (int a2 = 0; a2 < MT; ++a2) accU[a2][c2] = mfma4(dpT[a2][kk], hv, accU[a2][c2]);
+        for (int k = 0; k < NM; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+        }
       }
+      SCHED_PIN(2)   // region j
     }
-    // ---- EW(t-1): overlaps the independent MFMAs above ---------------------------------------
-    if (!LAST) ew(t - 1, eo);
-    SCHED_PIN(2)   // off-chain MFMAs + EW(t-1) + LDS writes issued
+    if (!LAST) ew_publish(t - 1, eo_out, dpo);
+    SCHED_PIN(3)   // LDS publish
     lds_barrier();
-    SCHED_PIN(3)   // barrier passed
+    SCHED_PIN(4)   // barrier passed
   };
 
+  f32x4 dpoE[MT], dpoO[MT];     // d_pre_s of even / odd s
+  EwOps eE, eO;                 // operands of EW(s) for even / odd s
+  XT xE, xO;                    // x_s^T for even / odd s
   {
-    EwOps e0;
-    load_ew(Tn - 1, e0);
-    ew(Tn - 1, e0);
+    EwOut o0;
+    if ((Tn - 1) & 1) {
+      load_ew(Tn - 1, eO); load_xt(Tn - 1, xO);
+      if (Tn >= 2) load_ew(Tn - 2, eE);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ew_chunk(j, eO, o0);
+      ew_publish(Tn - 1, o0, dpoO);
+    } else {
+      load_ew(Tn - 1, eE); load_xt(Tn - 1, xE);
+      if (Tn >= 2) load_ew(Tn - 2, eO);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ew_chunk(j, eE, o0);
+      ew_publish(Tn - 1, o0, dpoE);
+    }
   }
   lds_barrier();
-  for (int t = Tn - 1; t >= 1; --t) iter(std::false_type{}, t);
-  iter(std::true_type{}, 0);
+  {
+    // iteration t: d_x(t+1) from dpo[(t+1)&1]; dW(t) with x[t&1]; EW(t-1) with e[(t-1)&1] -> dpo[(t-1)&1];
+    // requests x_{t-1} -> x[(t-1)&1] and EW(t-2) operands -> e[t&1]
+    int t = Tn - 1;
+    if ((t & 1) && t >= 1) { iter(std::false_type{}, t, dpoE, eE, eO, xO, xE); --t; }
+    for (; t >= 2; t -= 2) {
+      iter(std::false_type{}, t, dpoO, eO, eE, xE, xO);
+      iter(std::false_type{}, t - 1, dpoE, eE, eO, xO, xE);
+    }
+    iter(std::true_type{}, 0, dpoO, eO, eE, xE, xO);
+  }
+  dx_partial(0, dpoE);
+  if (1 < Tn) finish_dx(1);
+  lds_barrier();
+  finish_dx(0);
 #ifdef FASTGRNN_DIAG_STAMPS
   if ((DIAG & 16) && blockIdx.x == 7 && l == 0) {
     for (int k = 0; k < 8; ++k) g_diag[wv][k] = dsum[k];
@@ -501,7 +566,8 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
   }
-  // dU / dW slabs: D row 4g+r of tile a is n = wv*HS + a*16 + 4g + r; column = c*16 + i
+  // dU / dW slabs: D row 4g+r of tile a is n = wv*HS + a*16 + 4g + r; lane i of column tile c
+  // is column i*NCT + c (dW: feature i*NFT + f2), so a lane's tiles are contiguous in memory
   {
     float* pu = part + (size_t)blockIdx.x * slab_stride(H, F);
     float* pw = pu + H * H;
@@ -511,9 +577,11 @@ __global__ __launch_bounds__(256) void bwd_scan_mfma(
       for (int r = 0; r < 4; ++r) {
         const int n = wv * HS + a * 16 + 4 * g + r;
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) pu[(size_t)n * H + c * 16 + i] = accU[a][c][r];
+        for (int v = 0; v < NCT / 4; ++v)
+          st4(pu + (size_t)n * H + i * NCT + 4 * v,
+              f32x4{accU[a][4 * v][r], accU[a][4 * v + 1][r], accU[a][4 * v + 2][r], accU[a][4 * v + 3][r]});
 #pragma unroll
-        for (int f2 = 0; f2 < NFT; ++f2) pw[(size_t)n * F + f2 * 16 + i] = accW[a][f2][r];
+        for (int f2 = 0; f2 < NFT; ++f2) pw[(size_t)n * F + i * NFT + f2] = accW[a][f2][r];
       }
   }
   // bias partials: sum over the 16 utterance lanes of each group

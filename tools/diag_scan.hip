@@ -85,12 +85,12 @@ void run_bwd(const char* tag, int T, int B) {
   if (DIAG & 16) {
     unsigned long long h[4][16];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag), sizeof(h));
-    const char* names[4] = {"dx finish + requests + LDS reads", "chain MFMA", "off-chain MFMA + EW + LDS write", "barrier wait"};
+    const char* names[5] = {"LDS reads + d_x MFMA", "requests + chain MFMA", "4 x (dW/dU MFMA || EW chunk)", "LDS publish", "barrier wait"};
     for (int wv = 0; wv < 4; ++wv) {
       unsigned long long tot = 0;
-      for (int k = 0; k < 4; ++k) tot += h[wv][k];
+      for (int k = 0; k < 5; ++k) tot += h[wv][k];
       printf("   wave %d: total %.0f cycles/step:", wv, (double)tot / T);
-      for (int k = 0; k < 4; ++k) printf("  [%s] %.0f", names[k], (double)h[wv][k] / T);
+      for (int k = 0; k < 5; ++k) printf("  [%s] %.0f", names[k], (double)h[wv][k] / T);
       printf("\n");
     }
   }
@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
   run_bwd<0>("production (pins + spread)", T, B);
   run_bwd<32>("no pins", T, B);
   run_bwd<64>("pins, no load spreading", T, B);
+  run_bwd<128>("pins, no MFMA/VALU interleave", T, B);
   run_fwd<16>("stamped", T, B, true);
   run_fwd<16>("stamped", T, B, false);
   run_fwd<0>("production (pins + spread)", T, B, true);
