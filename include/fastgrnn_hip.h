@@ -65,7 +65,8 @@ typedef enum fastgrnn_nonlinearity {
 } fastgrnn_nonlinearity;
 
 /* flags */
-#define FASTGRNN_FLAG_FORCE_GENERIC 1u  /* bypass the MFMA-tiled kernels (testing / A-B) */
+#define FASTGRNN_FLAG_FORCE_GENERIC 1u   /* bypass the MFMA-tiled kernels (testing / A-B) */
+#define FASTGRNN_FLAG_FORCE_F32_MFMA 2u  /* use the fp32-MFMA scan instead of the split-precision one */
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {
@@ -105,7 +106,9 @@ int fastgrnn_hip_abi_version(void);
 const char *fastgrnn_hip_status_string(int status);
 
 /* Which kernel family a descriptor dispatches to: 0 = generic LDS/VALU scan,
- * 1 = MFMA-tiled fp32 scan (16 utterances per workgroup, U in registers).
+ * 1 = fp32-MFMA scan (v_mfma_f32_16x16x4_f32; 16 utterances per workgroup, U in registers),
+ * 2 = split-precision scan: every fp32 operand as three exact bf16 planes, six
+ *     v_mfma_f32_16x16x32_bf16 terms per product, fp32 accumulation (error O(2^-24)).
  * direction: 0 forward, 1 backward.  Pure function of the descriptor. */
 int fastgrnn_hip_kernel_path(const fastgrnn_desc *d, int direction);
 

@@ -34,8 +34,11 @@ int check_ws(void* ws, size_t have, size_t need) {
   return FASTGRNN_OK;
 }
 
-bool use_mfma(const fastgrnn_desc* d, int direction) {
-  return !(d->flags & FASTGRNN_FLAG_FORCE_GENERIC) && mfma_supported(*d, direction);
+// 0 = generic scan, 1 = fp32-MFMA scan, 2 = split-precision scan on the bf16 matrix pipe
+int pick_path(const fastgrnn_desc* d, int direction) {
+  if (d->flags & FASTGRNN_FLAG_FORCE_GENERIC) return 0;
+  if (!(d->flags & FASTGRNN_FLAG_FORCE_F32_MFMA) && split_supported(*d, direction)) return 2;
+  return mfma_supported(*d, direction) ? 1 : 0;
 }
 
 }  // namespace
@@ -60,17 +63,25 @@ const char* fastgrnn_hip_status_string(int status) {
 
 int fastgrnn_hip_kernel_path(const fastgrnn_desc* d, int direction) {
   if (check_desc(d) != FASTGRNN_OK) return -1;
-  return use_mfma(d, direction) ? 1 : 0;
+  return pick_path(d, direction);
 }
 
 size_t fastgrnn_hip_forward_workspace_bytes(const fastgrnn_desc* d) {
   if (check_desc(d) != FASTGRNN_OK) return 0;
-  return use_mfma(d, 0) ? mfma_forward_ws(*d) : generic_forward_ws(*d);
+  switch (pick_path(d, 0)) {
+    case 2: return 0;
+    case 1: return mfma_forward_ws(*d);
+    default: return generic_forward_ws(*d);
+  }
 }
 
 size_t fastgrnn_hip_backward_workspace_bytes(const fastgrnn_desc* d) {
   if (check_desc(d) != FASTGRNN_OK) return 0;
-  return use_mfma(d, 1) ? mfma_backward_ws(*d) : generic_backward_ws(*d);
+  switch (pick_path(d, 1)) {
+    case 2: return split_backward_ws(*d);
+    case 1: return mfma_backward_ws(*d);
+    default: return generic_backward_ws(*d);
+  }
 }
 
 int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p, const void* x, const void* h0,
@@ -82,8 +93,11 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
   if (!x || !h0 || !hs) return FASTGRNN_ERR_NULL_POINTER;
   if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_forward_workspace_bytes(d)))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return use_mfma(d, 0) ? mfma_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s)
-                        : generic_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s);
+  switch (pick_path(d, 0)) {
+    case 2: return split_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s);
+    case 1: return mfma_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s);
+    default: return generic_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s);
+  }
 }
 
 int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p, const void* grad_hs,
@@ -99,8 +113,11 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   if (d->u_rank ? (!g->d_u1 || !g->d_u2) : !g->d_u) return FASTGRNN_ERR_NULL_POINTER;
   if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_backward_workspace_bytes(d)))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return use_mfma(d, 1) ? mfma_backward(*d, *p, grad_hs, x, hs, z_s, c_s, h0, *g, workspace, s)
-                        : generic_backward(*d, *p, grad_hs, x, hs, z_s, c_s, h0, *g, workspace, s);
+  switch (pick_path(d, 1)) {
+    case 2: return split_backward(*d, *p, grad_hs, x, hs, z_s, c_s, h0, *g, workspace, s);
+    case 1: return mfma_backward(*d, *p, grad_hs, x, hs, z_s, c_s, h0, *g, workspace, s);
+    default: return generic_backward(*d, *p, grad_hs, x, hs, z_s, c_s, h0, *g, workspace, s);
+  }
 }
 
 // Single-step operators are the T = 1 case of the unrolled ones: hs[0] = new_h, and the

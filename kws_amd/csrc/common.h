@@ -61,4 +61,13 @@ int mfma_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
                   const void* hs, const void* zs, const void* cs, const void* h0,
                   const fastgrnn_grads& g, void* ws, hipStream_t s);
 
+// split-precision (3 x bf16 planes, 6 MFMA terms) scan on the bf16 matrix pipe (kernels_split.hip)
+bool split_supported(const fastgrnn_desc& d, int direction);
+size_t split_backward_ws(const fastgrnn_desc& d);
+int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
+                  void* hs, void* zs, void* cs, void* ws, hipStream_t s);
+int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
+                   const void* hs, const void* zs, const void* cs, const void* h0,
+                   const fastgrnn_grads& g, void* ws, hipStream_t s);
+
 }  // namespace fastgrnn

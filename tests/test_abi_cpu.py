@@ -46,7 +46,8 @@ def _desc(**kw):
 def test_kernel_path_is_pure_and_respects_force_generic(lib):
     d = _desc()
     a = lib.fastgrnn_hip_kernel_path(C.byref(d), 0)
-    assert a in (0, 1) and a == lib.fastgrnn_hip_kernel_path(C.byref(d), 0)
+    assert a in (0, 1, 2) and a == lib.fastgrnn_hip_kernel_path(C.byref(d), 0)
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_FORCE_F32_MFMA)), 0) == 1
     d2 = _desc(flags=_lib.FLAG_FORCE_GENERIC)
     assert lib.fastgrnn_hip_kernel_path(C.byref(d2), 0) == 0
     assert lib.fastgrnn_hip_kernel_path(C.byref(d2), 1) == 0

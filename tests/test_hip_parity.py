@@ -26,6 +26,7 @@ DEV = "cuda:0"
 
 GATE_CODE = {"sigmoid": 0, "relu": 1, "tanh": 2, "quantTanh": 3, "quantSigm": 4, "quantSigm4": 5}
 FORCE_GENERIC = 1
+FORCE_F32_MFMA = 2
 
 
 def _t(a):
@@ -62,7 +63,7 @@ def _check_grads(g, ref, tol, tag):
         assert err <= tol, (tag, k, err)
 
 
-@pytest.mark.parametrize("flags", [0, FORCE_GENERIC], ids=["dispatch", "generic"])
+@pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
 def test_golden_vectors(golden, flags):
     """HIP vs the reference CPU cell's own outputs (tests/golden/*.npz)."""
     f64 = golden["dtype"] == "f64"
@@ -91,7 +92,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "T%dB%dF%dH%dr%d-%d%s" % c)
-@pytest.mark.parametrize("flags", [0, FORCE_GENERIC], ids=["dispatch", "generic"])
+@pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
 def test_seeded_vs_oracle_fp32(case, flags):
     T, B, F, H, rw, ru, gate = case
     rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
