@@ -67,6 +67,12 @@ typedef enum fastgrnn_nonlinearity {
 /* flags */
 #define FASTGRNN_FLAG_FORCE_GENERIC 1u   /* bypass the MFMA-tiled kernels (testing / A-B) */
 #define FASTGRNN_FLAG_FORCE_F32_MFMA 2u  /* use the fp32-MFMA scan instead of the split-precision one */
+/* Training-only contract between forward_unroll and backward_unroll (kernel path 2 only): the
+ * forward writes ONE auxiliary tensor, the pre-activation W.x_t + U.h_{t-1} (no bias), into z_s and
+ * ignores c_s; the backward reads it from z_s (c_s ignored, may be NULL), recomputes z_t and
+ * h_prime_t from it and therefore needs params->bias_gate / bias_update.  Saves one [T,B,H] write
+ * and one read per step against the reference operator's (z_s, h_prime_s) pair. */
+#define FASTGRNN_FLAG_SAVE_PREACT 4u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {

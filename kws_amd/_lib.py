@@ -17,6 +17,7 @@ ABI_VERSION = 1
 F32, F64 = 0, 1
 FLAG_FORCE_GENERIC = 1
 FLAG_FORCE_F32_MFMA = 2
+FLAG_SAVE_PREACT = 4
 
 # include/fastgrnn_hip.h: fastgrnn_nonlinearity.  0..2 are the reference's table
 # (rnn.py:478,751); 3..5 the CPU cell's quantised family (rnn.py:53-60).

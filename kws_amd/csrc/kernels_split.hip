@@ -105,7 +105,9 @@ __device__ __forceinline__ f32x4 mfma6(const Frag3& a, const Frag3& b, f32x4 acc
 // ------------------------------------------------------------------------------------------
 // forward  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
-template <int GATE, bool GATES_OUT, bool RAGGED>
+// AUX: 0 = hs only; 1 = also z_s, h_prime_s (the reference operator's outputs); 2 = also the
+// pre-activation W.x+U.h into zs (FASTGRNN_FLAG_SAVE_PREACT, consumed by bwd_scan_split<PREACT>).
+template <int GATE, int AUX, bool RAGGED>
 __global__ __launch_bounds__(256) void fwd_scan_split(
     int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -163,9 +165,12 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
       const size_t o = ((size_t)t * B + b) * H + n0;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
-      if (GATES_OUT) {
+      if (AUX == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
+      } else if (AUX == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);      // gt.z carries the pre-activation
       }
     }
   };
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
       for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma6(Uf[mt][s], hB[s], acc[mt]);          // .cu:368
     if (!FIRST) {
       // spread the store instructions of step t-1 evenly under the chain's 48 MFMAs
-      constexpr int NST = GATES_OUT ? 3 * MT : MT, NM = KS * MT * 6, PER = NM / (NST + 1);
+      constexpr int NST = (AUX == 1 ? 3 : AUX == 2 ? 2 : 1) * MT, NM = KS * MT * 6, PER = NM / (NST + 1);
 #pragma unroll
       for (int j = 0; j < NST; ++j) {
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
         const float z = gate_act<GATE>(pre + bzv[mt][r]);
         const float c = ftanh(pre + bhv[mt][r]);
         hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
-        gout.z[mt][r] = z; gout.c[mt][r] = c;
+        gout.z[mt][r] = (AUX == 2) ? pre : z; gout.c[mt][r] = c;
       }
     }
     const Frag3 f = split3(hown[0], hown[1]);
@@ -240,37 +245,474 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward  (H = 128, F = 32)
+// ------------------------------------------------------------------------------------------
+template <typename Fn, int... Is>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time loop: the index is a constant expression inside the body ("i" asm operands need that)
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// floats per workgroup slab of backward partial sums, padded to 64: dU | dW | d_bz | d_bh | (zeta, nu)
+constexpr int SLAB = (128 * 128 + 128 * 32 + 2 * 128 + 2 + 63) & ~63;
+
+constexpr int ROW_H = 288;             // bytes per utterance row of a 128-wide bf16 plane (256 + 32 pad)
+constexpr int ROW_X = 96;              // bytes per utterance row of a 32-wide bf16 plane (64 + 32 pad)
+constexpr int PLANE_DP = 32 * ROW_H;   // d_pre planes carry 16 extra all-zero rows (see below)
+constexpr int PLANE_H = 16 * ROW_H;
+constexpr int PLANE_X = 16 * ROW_X;
+
+struct BwdSplitLds {
+  // natural [utterance][unit] images of exact bf16 planes, double-buffered by step parity.  Each is
+  // read two ways: as MFMA B fragments (ds_read_b128: 8 consecutive units of one utterance) and
+  // transposed (ds_read_b64_tr_b16: 8 consecutive utterances of one unit) for the K = utterance
+  // products dW, dU.  The MFMA's K is 32 but a tile has 16 utterances: rows 16..31 of the d_pre
+  // image (the A operand) are zero forever, so lane groups 2,3 contribute nothing.
+  unsigned char DP[2][3 * PLANE_DP];   // d_pre_t
+  unsigned char HP[2][3 * PLANE_H];    // h_{t-1}
+  unsigned char XP[2][3 * PLANE_X];    // x_t
+  f32x4 DX[2][4][2][64];               // d_x partial sums of every wave, per feature tile
+  float red[8];
+};
+
+// One transposed fragment = two ds_read_b64_tr_b16 (utterance rows +0..3 and +4..7 of this lane's
+// 8-row block; EXEC is all ones everywhere these are used).  hipcc does not count asm loads in its
+// lgkmcnt bookkeeping: every consumer sits behind tr_wait(), which names the destinations.
+template <int OFF, int ROWB>
+__device__ __forceinline__ void tr_read2(unsigned long long& lo, unsigned long long& hi, unsigned base) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=v"(lo), "=v"(hi)
+               : "v"(base), "i"(OFF), "i"(OFF + 4 * ROWB)
+               : "memory");
+}
+__device__ __forceinline__ void tr_wait(unsigned long long (&lo)[3], unsigned long long (&hi)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2])::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ u32x4 join(unsigned long long lo, unsigned long long hi) {
+  return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+}
+
+// Reverse scan, pipelined like bwd_scan_mfma (kernels_mfma.hip): iteration t runs the dependent
+// chain d_h = z*g + U^T d_pre_t (48 MFMAs), then the independent dW/dU MFMAs of step t (120) on the
+// matrix pipe WHILE the VALU computes EW(t-1) and splits d_pre_{t-1}, h_{t-2}, x_{t-1} into planes.
+// PREACT: aux0 holds the pre-activation W x + U h saved by the forward (one tensor) and z, c are
+// recomputed here; otherwise aux0 = z_s, aux1 = h_prime_s (the reference operator's tensors).
+template <int GATE, bool PREACT, bool RAGGED>
+__global__ __launch_bounds__(256) void bwd_scan_split(
+    int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ x,
+    const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
+    const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
+    const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ d_x, float* __restrict__ d_h0, float* __restrict__ part) {
+  constexpr int H = 128, F = 32, MT = 2, KS = 4, NCT = 8, NFT = 2;
+  __shared__ BwdSplitLds S;
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 32 + g * 8;                    // this lane's 8 hidden units
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+  // zero rows 16..31 of every d_pre plane (never written afterwards)
+  for (int idx = tid; idx < 2 * 3 * 16 * (ROW_H / 4); idx += 256) {
+    const int row = idx % (16 * (ROW_H / 4)), pl = idx / (16 * (ROW_H / 4));     // pl = buffer*3 + plane
+    reinterpret_cast<unsigned*>(&S.DP[pl / 3][(pl % 3) * PLANE_DP + 16 * ROW_H])[row] = 0u;
+  }
+
+  // ---- resident A operands ------------------------------------------------------------------
+  // chain: d_h[k][b] = sum_n U[n][k] d_pre[b][n]; A row i of tile mt is k = 32wv + 8(i>>2) + 4mt + (i&3)
+  Frag3 UTf[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int kA = wv * 32 + (i >> 2) * 8 + mt * 4 + (i & 3);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = u[(size_t)(32 * s + 8 * g + j) * H + kA];
+        hi[j] = u[(size_t)(32 * s + 8 * g + 4 + j) * H + kA];
+      }
+      UTf[mt][s] = split3(lo, hi);
+    }
+  }
+  // d_x[f][b] = sum_n W[n][f] d_pre[b][n] over this wave's own units: the K-step is the lane's own fragment
+  Frag3 WTf[NFT];
+#pragma unroll
+  for (int f2 = 0; f2 < NFT; ++f2) {
+    f32x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo[j] = w[(size_t)(n0 + j) * F + f2 * 16 + i];
+      hi[j] = w[(size_t)(n0 + 4 + j) * F + f2 * 16 + i];
+    }
+    WTf[f2] = split3(lo, hi);
+  }
+  f32x4 bzv[MT], bhv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    bzv[mt] = PREACT ? ld4(bz + n0 + 4 * mt) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bhv[mt] = PREACT ? ld4(bh + n0 + 4 * mt) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x4 accU[MT][NCT], accW[MT][NFT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) accU[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NFT; ++c) accW[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 sbz[MT], sbh[MT], dh[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
+  float pz = 0.f, pn = 0.f;
+
+  // lane-constant LDS byte offsets
+  const unsigned my_row_h = (unsigned)(i * ROW_H + n0 * 2);          // producer slot == B-fragment slot of (b=i, own units)
+  const int xb = wv * 4 + ((l >> 2) & 3), xf0 = (l & 3) * 8;         // x plane producer: row xb, features xf0..+7
+  const unsigned my_row_x = (unsigned)(xb * ROW_X + xf0 * 2);
+  const int q = (l & 15) >> 2, pp = l & 3;
+  const unsigned lds_dp = (unsigned)(size_t)&S.DP[0][0], lds_hp = (unsigned)(size_t)&S.HP[0][0];
+  const unsigned lds_xp = (unsigned)(size_t)&S.XP[0][0];
+  // transposed-read bases (buffer 0): A = d_pre^T rows 32wv + 16a + i, utterance block 8g (16..31 = zero rows);
+  // B = h_prev^T / x^T columns 16c + i, utterance block 8(g&1)
+  const unsigned trA0 = lds_dp + (8 * g + q) * ROW_H + (wv * 32 + 4 * pp) * 2;
+  const unsigned trH0 = lds_hp + (8 * (g & 1) + q) * ROW_H + (4 * pp) * 2;
+  const unsigned trX0 = lds_xp + (8 * (g & 1) + q) * ROW_X + (4 * pp) * 2;
+
+  struct EwOps { f32x4 g[MT], a0[MT], a1[MT], h[MT]; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev
+  struct XRaw { f32x4 lo, hi; };
+  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    const size_t o = ((size_t)t * B + bc) * H + n0;
+    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)B * H;   // .cu:478-481
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      e.g[mt] = ld4(ghs + o + 4 * mt);
+      e.a0[mt] = ld4(aux0 + o + 4 * mt);
+      if (!PREACT) e.a1[mt] = ld4(aux1 + o + 4 * mt);
+      e.h[mt] = ld4(hprev + 4 * mt);
+    }
+  };
+  auto load_xraw = [&](int t, XRaw& r) __attribute__((always_inline)) {
+    const int bb = blockIdx.x * 16 + xb;
+    const float* xp = x + ((size_t)t * B + ((!RAGGED || bb < B) ? bb : B - 1)) * F + xf0;
+    r.lo = ld4(xp); r.hi = ld4(xp + 4);
+  };
+
+  // EW(t): .cu:107-117.  Consumes dh = d_old_h from chain(t+1); leaves dh = z*g (C-in of chain(t));
+  // publishes the planes of d_pre_t, h_{t-1}, x_t in LDS buffers [t&1]; returns the planes of d_pre_t.
+  auto ew = [&](int t, const EwOps& e, const XRaw& xr, Frag3& dpo) __attribute__((always_inline)) {
+    const int buf = t & 1;
+    f32x4 dpv[MT], hpv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float z, c;
+        if (PREACT) {
+          z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
+          c = ftanh(e.a0[mt][r] + bhv[mt][r]);
+        } else {
+          z = e.a0[mt][r]; c = e.a1[mt][r];
+        }
+        const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
+        float hv = e.h[mt][r];
+        float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
+        float dzp = (hv - sz * c) * gate_dact<GATE>(z) * gg;                     // .cu:110
+        float zg = z * gg;                                                        // .cu:108
+        float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
+        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hv = 0.f; }
+        sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
+        dpv[mt][r] = dzp + dcp;                                                   // .cu:113
+        hpv[mt][r] = hv;
+        dh[mt][r] = zg;
+      }
+    }
+    dpo = split3(dpv[0], dpv[1]);
+    const Frag3 hf = split3(hpv[0], hpv[1]);
+    const Frag3 xf = split3(xr.lo, xr.hi);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<u32x4*>(&S.DP[buf][p * PLANE_DP + my_row_h]) = dpo.p[p];
+      *reinterpret_cast<u32x4*>(&S.HP[buf][p * PLANE_H + my_row_h]) = hf.p[p];
+      *reinterpret_cast<u32x4*>(&S.XP[buf][p * PLANE_X + my_row_x]) = xf.p[p];
+    }
+  };
+  // d_x partial of step t over this wave's units (.cu:538): register operands only
+  auto dx_partial = [&](int t, const Frag3& dpo) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f2 = 0; f2 < NFT; ++f2) S.DX[t & 1][wv][f2][l] = mfma6(WTf[f2], dpo, f32x4{0.f, 0.f, 0.f, 0.f});
+  };
+  auto finish_dx = [&](int t) __attribute__((always_inline)) {
+    if (wv < NFT) {                         // wave-uniform
+      f32x4 sacc = (S.DX[t & 1][0][wv][l] + S.DX[t & 1][1][wv][l]) + (S.DX[t & 1][2][wv][l] + S.DX[t & 1][3][wv][l]);
+      if (valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, sacc);
+    }
+  };
+
+  // dW += d_pre_t^T x_t, dU += d_pre_t^T h_{t-1} (.cu:539-540): 2 row tiles x (2 + 8) column tiles x 6 terms.
+  // Fragments come straight out of the plane images through the hardware transpose read; column
+  // tiles are software-pipelined one ahead (the asm reads are waited for explicitly).
+  auto weight_grads = [&](int t) __attribute__((always_inline)) {
+    const int buf = t & 1;
+    const unsigned trA = trA0 + buf * (3 * PLANE_DP), trH = trH0 + buf * (3 * PLANE_H), trX = trX0 + buf * (3 * PLANE_X);
+    unsigned long long alo[MT][3], ahi[MT][3], blo[2][3], bhi[2][3];
+    static_for<MT>([&](auto A2) {
+      static_for<3>([&](auto P) {
+        constexpr int a2 = decltype(A2)::value, pl = decltype(P)::value;
+        tr_read2<pl * PLANE_DP + a2 * 32, ROW_H>(alo[a2][pl], ahi[a2][pl], trA);
+      });
+    });
+    // column tile ct: 0,1 = feature tiles of dW (x image); 2..9 = unit tiles of dU (h_prev image)
+    auto issue = [&](auto CT, unsigned long long (&lo)[3], unsigned long long (&hi)[3]) __attribute__((always_inline)) {
+      constexpr int ct = decltype(CT)::value;
+      static_for<3>([&](auto P) {
+        constexpr int pl = decltype(P)::value;
+        if constexpr (ct < NFT) tr_read2<pl * PLANE_X + ct * 32, ROW_X>(lo[pl], hi[pl], trX);
+        else tr_read2<pl * PLANE_H + (ct - NFT) * 32, ROW_H>(lo[pl], hi[pl], trH);
+      });
+    };
+    issue(std::integral_constant<int, 0>{}, blo[0], bhi[0]);
+    tr_wait(alo[0], ahi[0]);
+    tr_wait(alo[1], ahi[1]);
+    tr_wait(blo[0], bhi[0]);
+    Frag3 Af[MT];
+#pragma unroll
+    for (int a2 = 0; a2 < MT; ++a2)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) Af[a2].p[pl] = join(alo[a2][pl], ahi[a2][pl]);
+    static_for<NFT + NCT>([&](auto CT) {
+      constexpr int ct = decltype(CT)::value, cur = ct & 1;
+      if constexpr (ct + 1 < NFT + NCT) issue(std::integral_constant<int, ct + 1>{}, blo[cur ^ 1], bhi[cur ^ 1]);
+      Frag3 Bf;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) Bf.p[pl] = join(blo[cur][pl], bhi[cur][pl]);
+#pragma unroll
+      for (int a2 = 0; a2 < MT; ++a2) {
+        if constexpr (ct < NFT) accW[a2][ct] = mfma6(Af[a2], Bf, accW[a2][ct]);
+        else accU[a2][ct - NFT] = mfma6(Af[a2], Bf, accU[a2][ct - NFT]);
+      }
+      if constexpr (ct + 1 < NFT + NCT) tr_wait(blo[cur ^ 1], bhi[cur ^ 1]);
+    });
+  };
+
+  // One pipelined iteration.  dpo holds the planes of d_pre_{t+1} on entry and receives those of
+  // d_pre_{t-1}; (eo, xr) are the operands of EW(t-1), requested an iteration ago; (e_load, x_load)
+  // receive those of EW(t-2).
+  auto iter = [&](auto last_tag, int t, Frag3& dpo, const EwOps& eo, EwOps& e_load, const XRaw& xr,
+                  XRaw& x_load) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int buf = t & 1;
+    // B operand of the chain: planes of d_pre_t for all units
+    Frag3 dB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dB[s].p[p] = *reinterpret_cast<const u32x4*>(&S.DP[buf][p * PLANE_DP + i * ROW_H + (32 * s + 8 * g) * 2]);
+    if (t + 1 < Tn) dx_partial(t + 1, dpo);          // register-only MFMAs cover the LDS round trip
+    __builtin_amdgcn_sched_barrier(0);
+    if (!LAST) {
+      load_xraw(t >= 2 ? t - 2 : 0, x_load);
+      load_ew(t >= 2 ? t - 2 : 0, e_load);
+    }
+    // ---- d_h chain (.cu:537): C-in = z*g --------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma6(UTf[mt][s], dB[s], dh[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < Tn) finish_dx(t + 2);               // published at the top of the previous iteration
+    weight_grads(t);                                 // 120 independent MFMAs on the matrix pipe ...
+    if (!LAST) ew(t - 1, eo, xr, dpo);               // ... while the VALU prepares step t-1
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+  };
+
+  Frag3 dpoE, dpoO;             // planes of d_pre_s for even / odd s
+  EwOps eE, eO;                 // operands of EW(s) for even / odd s
+  XRaw xE, xO;
+  if ((Tn - 1) & 1) {
+    load_ew(Tn - 1, eO); load_xraw(Tn - 1, xO);
+    if (Tn >= 2) { load_ew(Tn - 2, eE); load_xraw(Tn - 2, xE); }
+    ew(Tn - 1, eO, xO, dpoO);
+  } else {
+    load_ew(Tn - 1, eE); load_xraw(Tn - 1, xE);
+    if (Tn >= 2) { load_ew(Tn - 2, eO); load_xraw(Tn - 2, xO); }
+    ew(Tn - 1, eE, xE, dpoE);
+  }
+  __syncthreads();              // also orders the zero rows of the d_pre images
+  {
+    // iteration t: d_x(t+1) from dpo[(t+1)&1]; EW(t-1) with e[(t-1)&1], x[(t-1)&1] -> dpo[(t-1)&1];
+    // requests the operands of EW(t-2) into e[t&1], x[t&1]
+    int t = Tn - 1;
+    if ((t & 1) && t >= 1) { iter(std::false_type{}, t, dpoE, eE, eO, xE, xO); --t; }
+    for (; t >= 2; t -= 2) {
+      iter(std::false_type{}, t, dpoO, eO, eE, xO, xE);
+      iter(std::false_type{}, t - 1, dpoE, eE, eO, xE, xO);
+    }
+    iter(std::true_type{}, 0, dpoO, eO, eE, xO, xE);
+  }
+  dx_partial(0, dpoE);
+  if (1 < Tn) finish_dx(1);
+  lds_barrier();
+  finish_dx(0);
+  // ---- flush ---------------------------------------------------------------------------------
+  if (valid) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
+  }
+  // dU / dW slabs: D row 4g+r of tile a is n = 32wv + 16a + 4g + r; column = 16c + i
+  {
+    float* pu = part + (size_t)blockIdx.x * SLAB;
+    float* pw = pu + H * H;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = wv * 32 + a * 16 + 4 * g + r;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) pu[(size_t)n * H + c * 16 + i] = accU[a][c][r];
+#pragma unroll
+        for (int f2 = 0; f2 < NFT; ++f2) pw[(size_t)n * F + f2 * 16 + i] = accW[a][f2][r];
+      }
+  }
+  // bias partials: sum over the 16 utterance lanes of each group
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = sbz[mt][r], c = sbh[mt][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
+      if (i == 0) {
+        float* pb = part + (size_t)blockIdx.x * SLAB + H * H + H * F;
+        pb[n0 + 4 * mt + r] = a;
+        pb[H + n0 + 4 * mt + r] = c;
+      }
+    }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
+  if (l == 0) { S.red[wv] = pz; S.red[4 + wv] = pn; }
+  __syncthreads();
+  if (tid == 0) {
+    float* pzn = part + (size_t)blockIdx.x * SLAB + H * H + H * F + 2 * H;
+    pzn[0] = S.red[0] + S.red[1] + S.red[2] + S.red[3];
+    pzn[1] = S.red[4] + S.red[5] + S.red[6] + S.red[7];
+  }
+}
+
+// Deterministic reduction of the per-workgroup slabs in ONE launch (same scheme as kernels_mfma.hip).
+__global__ __launch_bounds__(1024) void reduce_slabs_split(int nwg, const float* __restrict__ part,
+                                                           const float* __restrict__ zeta, const float* __restrict__ nu,
+                                                           float* __restrict__ d_u, float* __restrict__ d_w,
+                                                           float* __restrict__ d_bz, float* __restrict__ d_bh,
+                                                           float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+  constexpr int H = 128, F = 32;
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, part_id = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
+  const int ntot = H * H + H * F + 2 * H + 2;
+  float a = 0.f;
+  if (idx < ntot) {
+    float v[8];
+    for (int wg0 = part_id; wg0 < nwg; wg0 += 16 * 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int wg = wg0 + 16 * j;
+        v[j] = wg < nwg ? part[(size_t)wg * SLAB + idx] : 0.f;
+      }
+      a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  sm[part_id][o] = a;
+  __syncthreads();
+  if (part_id == 0 && idx < ntot) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    const int oW = H * H, oBz = oW + H * F, oBh = oBz + H, oZ = oBh + H;
+    if (idx < oW) d_u[idx] = t;
+    else if (idx < oBz) d_w[idx - oW] = t;
+    else if (idx < oBh) d_bz[idx - oBz] = t;
+    else if (idx < oZ) d_bh[idx - oBh] = t;
+    else if (idx == oZ) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
+    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                      // .cu:117,545
+  }
+}
+
+template <int GATE>
+void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                     const void* a0, const void* a1, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
+  const int nwg = (d.B + 15) / 16;
+  dim3 grid(nwg), block(256);
+  const bool ragged = (d.B % 16) != 0, preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  float* part = reinterpret_cast<float*>(ws);
+  auto go = [&](auto kern) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)ghs, (const float*)x, (const float*)hs,
+                       (const float*)a0, (const float*)a1, (const float*)h0, (const float*)p.w, (const float*)p.u,
+                       (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
+                       (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
+  };
+  if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
+  else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
+  const int ntot = 128 * 128 + 128 * 32 + 2 * 128 + 2;
+  hipLaunchKernelGGL(reduce_slabs_split, dim3((ntot + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
+                     (const float*)p.nu, (float*)g.d_u, (float*)g.d_w, (float*)g.d_bias_gate,
+                     (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
+}
+
 template <int GATE>
 void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                      void* zs, void* cs, hipStream_t s) {
   dim3 grid((d.B + 15) / 16), block(256);
-  const bool ragged = (d.B % 16) != 0, gates = zs != nullptr;
+  const bool ragged = (d.B % 16) != 0;
+  const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
-  if (gates) { if (ragged) go(fwd_scan_split<GATE, true, true>); else go(fwd_scan_split<GATE, true, false>); }
-  else       { if (ragged) go(fwd_scan_split<GATE, false, true>); else go(fwd_scan_split<GATE, false, false>); }
+  if (aux == 1)      { if (ragged) go(fwd_scan_split<GATE, 1, true>); else go(fwd_scan_split<GATE, 1, false>); }
+  else if (aux == 2) { if (ragged) go(fwd_scan_split<GATE, 2, true>); else go(fwd_scan_split<GATE, 2, false>); }
+  else               { if (ragged) go(fwd_scan_split<GATE, 0, true>); else go(fwd_scan_split<GATE, 0, false>); }
 }
 
 }  // namespace
 
 bool split_supported(const fastgrnn_desc& d, int direction) {
-  return direction == 0 && d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
+  (void)direction;
+  return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
          d.update_nl == FASTGRNN_NL_TANH && d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH &&
          d.H == 128 && d.F == 32;
 }
 
-size_t split_backward_ws(const fastgrnn_desc&) { return 0; }
-int split_backward(const fastgrnn_desc&, const fastgrnn_params&, const void*, const void*, const void*, const void*,
-                   const void*, const void*, const fastgrnn_grads&, void*, hipStream_t) {
-  return FASTGRNN_ERR_UNSUPPORTED;
+size_t split_backward_ws(const fastgrnn_desc& d) { return align256((size_t)((d.B + 15) / 16) * SLAB * 4); }
+
+int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                   const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws,
+                   hipStream_t s) {
+  switch (d.gate_nl) {
+    case FASTGRNN_NL_SIGMOID: launch_bwd_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_RELU: launch_bwd_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    default: launch_bwd_gate<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+  }
+  return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
 
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                   void* zs, void* cs, void*, hipStream_t s) {
-  if ((zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
+  if (!(d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_fwd_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
     case FASTGRNN_NL_RELU: launch_fwd_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;

@@ -159,10 +159,11 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
                                    input.dtype, gate_nl, update_nl, flags)
     dev = input.device
     oshape = (T, B, H) if unrolled else (B, H)
+    preact = bool(flags & _lib.FLAG_SAVE_PREACT)
     with torch.cuda.device(dev):
         hs = torch.empty(oshape, dtype=input.dtype, device=dev)
-        zs = torch.empty(oshape, dtype=input.dtype, device=dev) if want_gates else None
-        cs = torch.empty(oshape, dtype=input.dtype, device=dev) if want_gates else None
+        zs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates or preact) else None
+        cs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates and not preact) else None
         nbytes = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))
         ws, wsp = _workspace(nbytes, dev)
         fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
@@ -173,12 +174,19 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         # ws was allocated by torch's caching allocator on this same (current) stream, so
         # its reuse after this function returns is stream-ordered behind the launches above.
         del ws
+    if preact:
+        return [hs, zs]          # zs holds the pre-activation W.x + U.h
     return [hs, zs, cs] if want_gates else [hs]
 
 
 def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w1, w2, u1, u2, gate_nl,
-                   unrolled, update_nl, flags):
+                   unrolled, update_nl, flags, bias_gate=None, bias_update=None):
     lib = _lib.load()
+    preact = bool(flags & _lib.FLAG_SAVE_PREACT)
+    if preact:
+        if bias_gate is None or bias_update is None:
+            raise RuntimeError("FLAG_SAVE_PREACT backward needs bias_gate and bias_update")
+        h_prime = z              # unused by the kernel; keeps the shape checks below uniform
     for t, n in ((grad_h, "grad_h"), (input, "input"), (hs_or_old_h, "hidden_states" if unrolled else "old_h"),
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
         _check_input(t, n)
@@ -197,9 +205,10 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
     for t in (grad_h, hs_or_old_h, z, h_prime, h0):
         if t.dtype != dt:
             raise RuntimeError("fastgrnn backward: operand dtypes differ")
-    # biases are not needed by the backward (z, h_prime are given); pass zeta as a dummy
-    desc, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2, zeta, zeta, zeta, nu,
-                                         dt, gate_nl, update_nl, flags)
+    # biases are not needed by the backward when z, h_prime are given: pass zeta as a dummy
+    desc, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2,
+                                         bias_gate if preact else zeta, bias_update if preact else zeta,
+                                         zeta, nu, dt, gate_nl, update_nl, flags)
     dev = input.device
     with torch.cuda.device(dev):
         mk = lambda *s: torch.empty(s, dtype=dt, device=dev)
@@ -221,8 +230,8 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         with _Timed("backward", dev):
             if unrolled:
                 st = lib.fastgrnn_hip_backward_unroll(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
-                                                      _ptr(hs_or_old_h), _ptr(z), _ptr(h_prime), _ptr(h0),
-                                                      C.byref(grads), wsp, nbytes, _stream(dev))
+                                                      _ptr(hs_or_old_h), _ptr(z), _ptr(None if preact else h_prime),
+                                                      _ptr(h0), C.byref(grads), wsp, nbytes, _stream(dev))
             else:
                 st = lib.fastgrnn_hip_backward(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
                                                _ptr(h0), _ptr(z), _ptr(h_prime), C.byref(grads), wsp, nbytes,
@@ -260,7 +269,11 @@ def forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_n
 
 
 def backward_unroll(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h, w1, w2, u1, u2,
-                    z_non_linearity, *, update_non_linearity=2, flags=0):
-    """fastgrnn_cuda.cpp:182-232 -> 12 tensors (.cu:556)."""
+                    z_non_linearity, *, update_non_linearity=2, flags=0, bias_gate=None, bias_update=None):
+    """fastgrnn_cuda.cpp:182-232 -> 12 tensors (.cu:556).  With ``flags & FLAG_SAVE_PREACT``
+    (extension, kernel path 2) ``z`` is the pre-activation tensor returned by
+    ``forward_unroll(..., flags=FLAG_SAVE_PREACT)``, ``h_prime`` is ignored and the two bias
+    tensors must be given."""
     return _backward_impl(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h,
-                          w1, w2, u1, u2, z_non_linearity, True, update_non_linearity, flags)
+                          w1, w2, u1, u2, z_non_linearity, True, update_non_linearity, flags,
+                          bias_gate=bias_gate, bias_update=bias_update)

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import fastgrnn_cuda
+from . import _lib, fastgrnn_cuda
 
 NON_LINEARITY = {"sigmoid": 0, "relu": 1, "tanh": 2}   # rnn.py:478,751
 
@@ -61,26 +61,49 @@ class FastGRNNFunction(Function):
 
 
 class FastGRNNUnrollFunction(Function):
-    """rnn.py:907-972."""
+    """rnn.py:907-972.  Same inputs, same gradients; what is SAVED between the two passes is
+    an internal matter: on the split-precision kernel path the forward keeps one auxiliary
+    tensor (the pre-activation W.x+U.h) instead of the reference's two (z_s, h_prime_s) and the
+    backward recomputes the gates from it -- one [T,B,H] HBM write and read less per step."""
 
     @staticmethod
     def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity):
         input = input.contiguous()
         old_h = old_h.contiguous()
+        T, B, F = input.shape
+        H = old_h.shape[1]
+        rw = w1.shape[0] if w1.numel() else 0
+        ru = u1.shape[0] if u1.numel() else 0
+        preact = (input.dtype == torch.float32 and input.is_cuda and
+                  fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1) == 2)
+        flags = _lib.FLAG_SAVE_PREACT if preact else 0
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
-                                               gate_non_linearity, w1, w2, u1, u2)
+                                               gate_non_linearity, w1, w2, u1, u2, flags=flags)
         hidden_states = outputs[0]
-        variables = [input, hidden_states, zeta, nu, w, u] + outputs[1:] + [old_h, w1, w2, u1, u2]
+        if preact:
+            variables = [input, hidden_states, zeta, nu, w, u, outputs[1], bias_gate, bias_update,
+                         old_h, w1, w2, u1, u2]
+        else:
+            variables = [input, hidden_states, zeta, nu, w, u] + outputs[1:] + [old_h, w1, w2, u1, u2]
         ctx.save_for_backward(*variables)
         ctx.gate_non_linearity = gate_non_linearity
+        ctx.preact = preact
         return hidden_states
 
     @staticmethod
     def backward(ctx, grad_h):
-        (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
-        outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
-                                                z_s, h_prime_s, old_h, w1, w2, u1, u2,
-                                                ctx.gate_non_linearity)
+        if ctx.preact:
+            (input, hidden_states, zeta, nu, w, u, pre_s, bias_gate, bias_update, old_h,
+             w1, w2, u1, u2) = ctx.saved_tensors
+            outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
+                                                    pre_s, pre_s, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
+                                                    flags=_lib.FLAG_SAVE_PREACT, bias_gate=bias_gate,
+                                                    bias_update=bias_update)
+        else:
+            (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
+            outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
+                                                    z_s, h_prime_s, old_h, w1, w2, u1, u2,
+                                                    ctx.gate_non_linearity)
         return _as_autograd_grads(outputs, ctx.needs_input_grad)
 
 

@@ -137,6 +137,38 @@ def test_seeded_vs_oracle_fp64(lowrank):
     _check_grads(g, g_o, 1e-10, "fp64")
 
 
+@pytest.mark.parametrize("B", [64, 45])
+def test_preact_mode_vs_oracle(B):
+    """FLAG_SAVE_PREACT (kernel path 2): forward saves W.x+U.h only; backward recomputes z, h_prime."""
+    T, F, H = 99, 32, 128
+    if fastgrnn_cuda.kernel_path(T, B, F, H, direction=1) != 2:
+        pytest.skip("split-precision path not dispatched for this shape")
+    rng = np.random.default_rng(21)
+    p = O.make_params(F, H, dtype=np.float32, seed=13, randomize_scalars=True)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    P = _param_tensors(p)
+    xt, ht, Gt = _t(x), _t(h0), _t(G)
+    SAVE_PREACT = 4
+    hs, pre = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                           0, P["w1"], P["w2"], P["u1"], P["u2"], flags=SAVE_PREACT)
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=SAVE_PREACT,
+                                         bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64, h64 = x.astype(np.float64), h0.astype(np.float64)
+    hs_o, zs_o, cs_o = O.unroll_forward(x64, p64, h64)
+    hprev = np.concatenate([h64[None], hs_o[:-1]], 0)
+    pre_o = x64 @ p64["w"].T + hprev @ p64["u"].T
+    assert np.abs(hs.cpu().numpy() - hs_o).max() <= 1e-5
+    assert np.abs(pre.cpu().numpy() - pre_o).max() <= 1e-5
+    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+    g = {n: o.cpu().numpy() for n, o in zip(names, outs[:8])}
+    _check_grads(g, g_o, 2e-5, "preact")
+
+
 def test_single_step_operators():
     """forward / backward (fastgrnn_cuda.cpp:73-145) == T=1 oracle."""
     B, F, H = 37, 32, 128
