@@ -248,6 +248,20 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
 // ------------------------------------------------------------------------------------------
 // backward  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
+#ifdef FASTGRNN_DIAG_STAMPS
+// Diagnostic build only (tools/diag_split.hip): per-segment cycle sums of each wave of block 7.
+__device__ unsigned long long g_sdiag[4][8];
+#define SPLIT_STAMP(idx)                                                                  \
+  {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long now_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    dsum[idx] += now_ - dlast; dlast = now_;                                              \
+  }
+#else
+#define SPLIT_STAMP(idx)
+#endif
 template <typename Fn, int... Is>
 __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -261,26 +275,27 @@ constexpr int SLAB = (128 * 128 + 128 * 32 + 2 * 128 + 2 + 63) & ~63;
 
 constexpr int ROW_H = 288;             // bytes per utterance row of a 128-wide bf16 plane (256 + 32 pad)
 constexpr int ROW_X = 96;              // bytes per utterance row of a 32-wide bf16 plane (64 + 32 pad)
-constexpr int PLANE_DP = 32 * ROW_H;   // d_pre planes carry 16 extra all-zero rows (see below)
-constexpr int PLANE_H = 16 * ROW_H;
-constexpr int PLANE_X = 16 * ROW_X;
+constexpr int PLANE_H = 16 * ROW_H;    // 4608
+constexpr int PLANE_X = 16 * ROW_X;    // 1536
+constexpr int IMG = 2 * 3 * PLANE_H + 3 * PLANE_X;   // one step's images: d_pre | h_prev | x  (32256 B)
 
 struct BwdSplitLds {
-  // natural [utterance][unit] images of exact bf16 planes, double-buffered by step parity.  Each is
-  // read two ways: as MFMA B fragments (ds_read_b128: 8 consecutive units of one utterance) and
-  // transposed (ds_read_b64_tr_b16: 8 consecutive utterances of one unit) for the K = utterance
-  // products dW, dU.  The MFMA's K is 32 but a tile has 16 utterances: rows 16..31 of the d_pre
-  // image (the A operand) are zero forever, so lane groups 2,3 contribute nothing.
-  unsigned char DP[2][3 * PLANE_DP];   // d_pre_t
-  unsigned char HP[2][3 * PLANE_H];    // h_{t-1}
-  unsigned char XP[2][3 * PLANE_X];    // x_t
+  // Per step s, buffer s&3: natural [utterance][unit] images of the exact bf16 planes of d_pre_s,
+  // h_{s-1} and x_s.  Each is read two ways: as MFMA B fragments (ds_read_b128: 8 consecutive units
+  // of one utterance, the chain) and transposed (ds_read_b64_tr_b16: 8 consecutive utterances of
+  // one unit) for the K = utterance products dW, dU.  The MFMA's K is 32 and a tile has 16
+  // utterances, so dW/dU contract TWO consecutive steps per MFMA (lane groups 0,1 = step s+1,
+  // groups 2,3 = step s); four buffers keep a pair readable for the two iterations that share it.
+  unsigned char img[4][IMG];
   f32x4 DX[2][4][2][64];               // d_x partial sums of every wave, per feature tile
   float red[8];
 };
+constexpr int OFF_DP = 0, OFF_HP = 3 * PLANE_H, OFF_XP = 6 * PLANE_H;
 
-// One transposed fragment = two ds_read_b64_tr_b16 (utterance rows +0..3 and +4..7 of this lane's
-// 8-row block; EXEC is all ones everywhere these are used).  hipcc does not count asm loads in its
-// lgkmcnt bookkeeping: every consumer sits behind tr_wait(), which names the destinations.
+// One transposed half fragment (4 bf16: utterances +0..3 of this lane's 4-row block, one unit
+// column) per ds_read_b64_tr_b16; EXEC is all ones everywhere these are used.  hipcc does not count
+// asm loads in its lgkmcnt bookkeeping: every consumer sits behind tr_wait(), which names the
+// destinations.
 template <int OFF, int ROWB>
 __device__ __forceinline__ void tr_read2(unsigned long long& lo, unsigned long long& hi, unsigned base) {
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
@@ -298,9 +313,12 @@ __device__ __forceinline__ u32x4 join(unsigned long long lo, unsigned long long 
   return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
 }
 
-// Reverse scan, pipelined like bwd_scan_mfma (kernels_mfma.hip): iteration t runs the dependent
-// chain d_h = z*g + U^T d_pre_t (48 MFMAs), then the independent dW/dU MFMAs of step t (120) on the
-// matrix pipe WHILE the VALU computes EW(t-1) and splits d_pre_{t-1}, h_{t-2}, x_{t-1} into planes.
+// Reverse scan, pipelined like bwd_scan_mfma (kernels_mfma.hip).  Iteration t:
+//   top    B fragments of d_pre_t (LDS); 12 register-only d_x(t+1) MFMAs cover the round trip
+//   chain  d_h = z*g + U^T d_pre_t: 48 MFMAs (2 dependent chains); global requests in their shadow
+//   5 x    { 12 independent dW/dU MFMAs of one column tile of a step PAIR  ||  a slice of EW(t-1) }
+//   end    planes of d_pre_{t-1}, h_{t-2}, x_{t-1} published; one raw barrier
+// Even t does column tiles 0..4 of pair (t+1, t), odd t tiles 5..9 of pair (t+2, t+1).
 // PREACT: aux0 holds the pre-activation W x + U h saved by the forward (one tensor) and z, c are
 // recomputed here; otherwise aux0 = z_s, aux1 = h_prime_s (the reference operator's tensors).
 template <int GATE, bool PREACT, bool RAGGED>
@@ -322,10 +340,9 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   const int bc = valid ? b : B - 1;
   const int n0 = wv * 32 + g * 8;                    // this lane's 8 hidden units
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
-  // zero rows 16..31 of every d_pre plane (never written afterwards)
-  for (int idx = tid; idx < 2 * 3 * 16 * (ROW_H / 4); idx += 256) {
-    const int row = idx % (16 * (ROW_H / 4)), pl = idx / (16 * (ROW_H / 4));     // pl = buffer*3 + plane
-    reinterpret_cast<unsigned*>(&S.DP[pl / 3][(pl % 3) * PLANE_DP + 16 * ROW_H])[row] = 0u;
+  // Odd T: step T-1 has no partner; it is paired with a virtual step T whose images are zero.
+  if (Tn & 1) {
+    for (int idx = tid; idx < IMG / 4; idx += 256) reinterpret_cast<unsigned*>(&S.img[Tn & 3][0])[idx] = 0u;
   }
 
   // ---- resident A operands ------------------------------------------------------------------
@@ -377,18 +394,16 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   for (int mt = 0; mt < MT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
   float pz = 0.f, pn = 0.f;
 
-  // lane-constant LDS byte offsets
+  // lane-constant LDS byte offsets (within one step's image block)
+  const unsigned lds_img = (unsigned)(size_t)&S.img[0][0];
   const unsigned my_row_h = (unsigned)(i * ROW_H + n0 * 2);          // producer slot == B-fragment slot of (b=i, own units)
   const int xb = wv * 4 + ((l >> 2) & 3), xf0 = (l & 3) * 8;         // x plane producer: row xb, features xf0..+7
   const unsigned my_row_x = (unsigned)(xb * ROW_X + xf0 * 2);
   const int q = (l & 15) >> 2, pp = l & 3;
-  const unsigned lds_dp = (unsigned)(size_t)&S.DP[0][0], lds_hp = (unsigned)(size_t)&S.HP[0][0];
-  const unsigned lds_xp = (unsigned)(size_t)&S.XP[0][0];
-  // transposed-read bases (buffer 0): A = d_pre^T rows 32wv + 16a + i, utterance block 8g (16..31 = zero rows);
-  // B = h_prev^T / x^T columns 16c + i, utterance block 8(g&1)
-  const unsigned trA0 = lds_dp + (8 * g + q) * ROW_H + (wv * 32 + 4 * pp) * 2;
-  const unsigned trH0 = lds_hp + (8 * (g & 1) + q) * ROW_H + (4 * pp) * 2;
-  const unsigned trX0 = lds_xp + (8 * (g & 1) + q) * ROW_X + (4 * pp) * 2;
+  // transposed-read offsets: utterance block 8(g&1) of the step that this lane group covers
+  const unsigned trA_off = OFF_DP + (8 * (g & 1) + q) * ROW_H + (wv * 32 + 4 * pp) * 2;   // d_pre^T rows 32wv + 16a + i
+  const unsigned trH_off = OFF_HP + (8 * (g & 1) + q) * ROW_H + (4 * pp) * 2;             // h_prev^T column 16c + i
+  const unsigned trX_off = OFF_XP + (8 * (g & 1) + q) * ROW_X + (4 * pp) * 2;             // x^T column 16f + i
 
   struct EwOps { f32x4 g[MT], a0[MT], a1[MT], h[MT]; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev
   struct XRaw { f32x4 lo, hi; };
@@ -409,43 +424,46 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     r.lo = ld4(xp); r.hi = ld4(xp + 4);
   };
 
-  // EW(t): .cu:107-117.  Consumes dh = d_old_h from chain(t+1); leaves dh = z*g (C-in of chain(t));
-  // publishes the planes of d_pre_t, h_{t-1}, x_t in LDS buffers [t&1]; returns the planes of d_pre_t.
-  auto ew = [&](int t, const EwOps& e, const XRaw& xr, Frag3& dpo) __attribute__((always_inline)) {
-    const int buf = t & 1;
-    f32x4 dpv[MT], hpv[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float z, c;
-        if (PREACT) {
-          z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
-          c = ftanh(e.a0[mt][r] + bhv[mt][r]);
-        } else {
-          z = e.a0[mt][r]; c = e.a1[mt][r];
-        }
-        const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
-        float hv = e.h[mt][r];
-        float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
-        float dzp = (hv - sz * c) * gate_dact<GATE>(z) * gg;                     // .cu:110
-        float zg = z * gg;                                                        // .cu:108
-        float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
-        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hv = 0.f; }
-        sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
-        dpv[mt][r] = dzp + dcp;                                                   // .cu:113
-        hpv[mt][r] = hv;
-        dh[mt][r] = zg;
-      }
+  // EW(t): .cu:107-117, in pieces that the caller drops between batches of independent MFMAs so
+  // that the VALU works while the matrix pipe does.  Consumes dh = d_old_h from chain(t+1); leaves
+  // dh = z*g (C-in of chain(t)); publishes the planes of d_pre_t, h_{t-1}, x_t in image buffer
+  // [t&3]; returns the planes of d_pre_t.
+  struct EwState { f32x4 dpv[MT], hpv[MT]; };
+  auto ew_elem = [&](int k, const EwOps& e, EwState& st) __attribute__((always_inline)) {   // element k = 0..7
+    const int mt = k >> 2, r = k & 3;
+    float z, c;
+    if (PREACT) {
+      z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
+      c = ftanh(e.a0[mt][r] + bhv[mt][r]);
+    } else {
+      z = e.a0[mt][r]; c = e.a1[mt][r];
     }
-    dpo = split3(dpv[0], dpv[1]);
-    const Frag3 hf = split3(hpv[0], hpv[1]);
+    const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
+    float hv = e.h[mt][r];
+    float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
+    float dzp = (hv - sz * c) * gate_dact<GATE>(z) * gg;                     // .cu:110
+    float zg = z * gg;                                                        // .cu:108
+    float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
+    if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hv = 0.f; }
+    sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
+    st.dpv[mt][r] = dzp + dcp;                                                // .cu:113
+    st.hpv[mt][r] = hv;
+    dh[mt][r] = zg;
+  };
+  auto ew_publish_dp = [&](int t, const EwState& st, Frag3& dpo) __attribute__((always_inline)) {
+    dpo = split3(st.dpv[0], st.dpv[1]);
+    unsigned char* im = &S.img[t & 3][0];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(im + OFF_DP + p * PLANE_H + my_row_h) = dpo.p[p];
+  };
+  auto ew_publish_hx = [&](int t, const EwState& st, const XRaw& xr) __attribute__((always_inline)) {
+    const Frag3 hf = split3(st.hpv[0], st.hpv[1]);
     const Frag3 xf = split3(xr.lo, xr.hi);
+    unsigned char* im = &S.img[t & 3][0];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      *reinterpret_cast<u32x4*>(&S.DP[buf][p * PLANE_DP + my_row_h]) = dpo.p[p];
-      *reinterpret_cast<u32x4*>(&S.HP[buf][p * PLANE_H + my_row_h]) = hf.p[p];
-      *reinterpret_cast<u32x4*>(&S.XP[buf][p * PLANE_X + my_row_x]) = xf.p[p];
+      *reinterpret_cast<u32x4*>(im + OFF_HP + p * PLANE_H + my_row_h) = hf.p[p];
+      *reinterpret_cast<u32x4*>(im + OFF_XP + p * PLANE_X + my_row_x) = xf.p[p];
     }
   };
   // d_x partial of step t over this wave's units (.cu:538): register operands only
@@ -460,20 +478,22 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     }
   };
 
-  // dW += d_pre_t^T x_t, dU += d_pre_t^T h_{t-1} (.cu:539-540): 2 row tiles x (2 + 8) column tiles x 6 terms.
-  // Fragments come straight out of the plane images through the hardware transpose read; column
-  // tiles are software-pipelined one ahead (the asm reads are waited for explicitly).
-  auto weight_grads = [&](int t) __attribute__((always_inline)) {
-    const int buf = t & 1;
-    const unsigned trA = trA0 + buf * (3 * PLANE_DP), trH = trH0 + buf * (3 * PLANE_H), trX = trX0 + buf * (3 * PLANE_X);
+  // dW += d_pre_s^T x_s, dU += d_pre_s^T h_{s-1} (.cu:539-540) for the step pair (sU, sU-1): column tiles
+  // [5*HALF, 5*HALF+5) of the 10 (2 feature tiles of dW, 8 unit tiles of dU), 2 row tiles, 6 terms.
+  // Fragments come straight out of the plane images through the hardware transpose read, software-
+  // pipelined one column tile ahead; between(CT) is a slice of VALU work for the same region.
+  auto weight_grads = [&](auto half_tag, int sU, auto&& between) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(half_tag)::value, C0 = 5 * HALF;
+    // lane groups 0,1 read step sU's images, groups 2,3 step sU-1's
+    const unsigned im = lds_img + (unsigned)(((g < 2) ? sU : sU - 1) & 3) * IMG;
+    const unsigned trA = im + trA_off, trH = im + trH_off, trX = im + trX_off;
     unsigned long long alo[MT][3], ahi[MT][3], blo[2][3], bhi[2][3];
     static_for<MT>([&](auto A2) {
       static_for<3>([&](auto P) {
         constexpr int a2 = decltype(A2)::value, pl = decltype(P)::value;
-        tr_read2<pl * PLANE_DP + a2 * 32, ROW_H>(alo[a2][pl], ahi[a2][pl], trA);
+        tr_read2<pl * PLANE_H + a2 * 32, ROW_H>(alo[a2][pl], ahi[a2][pl], trA);
       });
     });
-    // column tile ct: 0,1 = feature tiles of dW (x image); 2..9 = unit tiles of dU (h_prev image)
     auto issue = [&](auto CT, unsigned long long (&lo)[3], unsigned long long (&hi)[3]) __attribute__((always_inline)) {
       constexpr int ct = decltype(CT)::value;
       static_for<3>([&](auto P) {
@@ -482,7 +502,7 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
         else tr_read2<pl * PLANE_H + (ct - NFT) * 32, ROW_H>(lo[pl], hi[pl], trH);
       });
     };
-    issue(std::integral_constant<int, 0>{}, blo[0], bhi[0]);
+    issue(std::integral_constant<int, C0>{}, blo[0], bhi[0]);
     tr_wait(alo[0], ahi[0]);
     tr_wait(alo[1], ahi[1]);
     tr_wait(blo[0], bhi[0]);
@@ -491,9 +511,9 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     for (int a2 = 0; a2 < MT; ++a2)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) Af[a2].p[pl] = join(alo[a2][pl], ahi[a2][pl]);
-    static_for<NFT + NCT>([&](auto CT) {
-      constexpr int ct = decltype(CT)::value, cur = ct & 1;
-      if constexpr (ct + 1 < NFT + NCT) issue(std::integral_constant<int, ct + 1>{}, blo[cur ^ 1], bhi[cur ^ 1]);
+    static_for<5>([&](auto J) {
+      constexpr int j = decltype(J)::value, ct = C0 + j, cur = j & 1;
+      if constexpr (j + 1 < 5) issue(std::integral_constant<int, ct + 1>{}, blo[cur ^ 1], bhi[cur ^ 1]);
       Frag3 Bf;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) Bf.p[pl] = join(blo[cur][pl], bhi[cur][pl]);
@@ -502,26 +522,38 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
         if constexpr (ct < NFT) accW[a2][ct] = mfma6(Af[a2], Bf, accW[a2][ct]);
         else accU[a2][ct - NFT] = mfma6(Af[a2], Bf, accU[a2][ct - NFT]);
       }
-      if constexpr (ct + 1 < NFT + NCT) tr_wait(blo[cur ^ 1], bhi[cur ^ 1]);
+      between(J);
+      // in-order issue: a VALU slice only overlaps the matrix pipe if it sits BETWEEN the MFMAs
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
+      }
+      if constexpr (j + 1 < 5) tr_wait(blo[cur ^ 1], bhi[cur ^ 1]);
     });
   };
 
-  // One pipelined iteration.  dpo holds the planes of d_pre_{t+1} on entry and receives those of
-  // d_pre_{t-1}; (eo, xr) are the operands of EW(t-1), requested an iteration ago; (e_load, x_load)
-  // receive those of EW(t-2).
-  auto iter = [&](auto last_tag, int t, Frag3& dpo, const EwOps& eo, EwOps& e_load, const XRaw& xr,
+  // One pipelined iteration (see the header).  dpo holds the planes of d_pre_{t+1} on entry and
+  // receives those of d_pre_{t-1}; (eo, xr) are the operands of EW(t-1), requested an iteration ago;
+  // (e_load, x_load) receive those of EW(t-2).  EVEN = (t & 1) == 0.
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
+  auto iter = [&](auto last_tag, auto even_tag, int t, Frag3& dpo, const EwOps& eo, EwOps& e_load, const XRaw& xr,
                   XRaw& x_load) __attribute__((always_inline)) {
-    constexpr bool LAST = decltype(last_tag)::value;
-    const int buf = t & 1;
+    constexpr bool LAST = decltype(last_tag)::value, EVEN = decltype(even_tag)::value;
     // B operand of the chain: planes of d_pre_t for all units
+    const unsigned char* im = &S.img[t & 3][0];
     Frag3 dB[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        dB[s].p[p] = *reinterpret_cast<const u32x4*>(&S.DP[buf][p * PLANE_DP + i * ROW_H + (32 * s + 8 * g) * 2]);
+        dB[s].p[p] = *reinterpret_cast<const u32x4*>(im + OFF_DP + p * PLANE_H + i * ROW_H + (32 * s + 8 * g) * 2);
     if (t + 1 < Tn) dx_partial(t + 1, dpo);          // register-only MFMAs cover the LDS round trip
     __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(0)
     if (!LAST) {
       load_xraw(t >= 2 ? t - 2 : 0, x_load);
       load_ew(t >= 2 ? t - 2 : 0, e_load);
@@ -532,38 +564,68 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma6(UTf[mt][s], dB[s], dh[mt]);
     __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
     if (t + 2 < Tn) finish_dx(t + 2);               // published at the top of the previous iteration
-    weight_grads(t);                                 // 120 independent MFMAs on the matrix pipe ...
-    if (!LAST) ew(t - 1, eo, xr, dpo);               // ... while the VALU prepares step t-1
+    SPLIT_STAMP(2)
+    // five column tiles x 12 independent MFMAs on the matrix pipe; between them the VALU prepares
+    // step t-1: two pieces per tile (8 elements, then the two plane publishes)
+    EwState st;
+    auto pieces = [&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (!LAST) {
+        if constexpr (j < 4) { ew_elem(2 * j, eo, st); ew_elem(2 * j + 1, eo, st); }
+        else { ew_publish_dp(t - 1, st, dpo); ew_publish_hx(t - 1, st, xr); }
+      }
+    };
+    const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
+    if constexpr (EVEN) {
+      weight_grads(std::integral_constant<int, 0>{}, t + 1, pieces);            // pair (t+1, t), tiles 0..4
+    } else {
+      if (t + 2 <= top) weight_grads(std::integral_constant<int, 1>{}, t + 2, pieces);   // pair (t+2, t+1), tiles 5..9
+      else { static_for<5>(pieces); }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(3)
     lds_barrier();
+    SPLIT_STAMP(4)
   };
 
   Frag3 dpoE, dpoO;             // planes of d_pre_s for even / odd s
   EwOps eE, eO;                 // operands of EW(s) for even / odd s
   XRaw xE, xO;
-  if ((Tn - 1) & 1) {
-    load_ew(Tn - 1, eO); load_xraw(Tn - 1, xO);
-    if (Tn >= 2) { load_ew(Tn - 2, eE); load_xraw(Tn - 2, xE); }
-    ew(Tn - 1, eO, xO, dpoO);
-  } else {
-    load_ew(Tn - 1, eE); load_xraw(Tn - 1, xE);
-    if (Tn >= 2) { load_ew(Tn - 2, eO); load_xraw(Tn - 2, xO); }
-    ew(Tn - 1, eE, xE, dpoE);
+  {
+    EwState st;
+    if ((Tn - 1) & 1) {
+      load_ew(Tn - 1, eO); load_xraw(Tn - 1, xO);
+      if (Tn >= 2) { load_ew(Tn - 2, eE); load_xraw(Tn - 2, xE); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ew_elem(k, eO, st);
+      ew_publish_dp(Tn - 1, st, dpoO); ew_publish_hx(Tn - 1, st, xO);
+    } else {
+      load_ew(Tn - 1, eE); load_xraw(Tn - 1, xE);
+      if (Tn >= 2) { load_ew(Tn - 2, eO); load_xraw(Tn - 2, xO); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ew_elem(k, eE, st);
+      ew_publish_dp(Tn - 1, st, dpoE); ew_publish_hx(Tn - 1, st, xE);
+    }
   }
-  __syncthreads();              // also orders the zero rows of the d_pre images
+  __syncthreads();              // also orders the zeroed virtual-step images
   {
     // iteration t: d_x(t+1) from dpo[(t+1)&1]; EW(t-1) with e[(t-1)&1], x[(t-1)&1] -> dpo[(t-1)&1];
     // requests the operands of EW(t-2) into e[t&1], x[t&1]
     int t = Tn - 1;
-    if ((t & 1) && t >= 1) { iter(std::false_type{}, t, dpoE, eE, eO, xE, xO); --t; }
+    if ((t & 1) && t >= 1) { iter(std::false_type{}, std::false_type{}, t, dpoE, eE, eO, xE, xO); --t; }
     for (; t >= 2; t -= 2) {
-      iter(std::false_type{}, t, dpoO, eO, eE, xO, xE);
-      iter(std::false_type{}, t - 1, dpoE, eE, eO, xE, xO);
+      iter(std::false_type{}, std::true_type{}, t, dpoO, eO, eE, xO, xE);
+      iter(std::false_type{}, std::false_type{}, t - 1, dpoE, eE, eO, xE, xO);
     }
-    iter(std::true_type{}, 0, dpoO, eO, eE, xO, xE);
+    iter(std::true_type{}, std::true_type{}, 0, dpoO, eO, eE, xO, xE);
   }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
+#endif
   dx_partial(0, dpoE);
+  weight_grads(std::integral_constant<int, 1>{}, 1, [&](auto) __attribute__((always_inline)) {});   // pair (1, 0), tiles 5..9
   if (1 < Tn) finish_dx(1);
   lds_barrier();
   finish_dx(0);

@@ -60,7 +60,11 @@ def _check_grads(g, ref, tol, tag):
     for k, v in ref.items():
         scale = max(1.0, float(np.abs(v).max()))
         err = float(np.abs(g[k].reshape(v.shape) - v).max()) / scale
-        assert err <= tol, (tag, k, err)
+        # d_zeta / d_nu are ONE scalar each: a sum of T*B*H random-sign terms, i.e. |sum| is
+        # ~sqrt(N) times smaller than the sum of magnitudes and an fp32 accumulation (the
+        # reference's included) is only good to ~sqrt(N) * 6e-8 relative to it
+        lim = max(tol, 1e-4) if (k in ("d_zeta", "d_nu") and g[k].dtype != np.float64) else tol
+        assert err <= lim, (tag, k, err)
 
 
 @pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
@@ -372,13 +376,17 @@ def test_full_size_backward_linearity_and_shard_sum():
         parts.append(_bwd(Gs, xs, hs_s, zs_s, cs_s, P, hz))
     for i in (1, 2, 3, 4, 6, 7):   # d_bias_z, d_bias_h, d_zeta, d_nu, d_w, d_u
         s = parts[0][i] + parts[1][i]
-        assert (s - g1[i]).abs().max() <= 2e-5 * max(1.0, float(g1[i].abs().max())), i
+        # the two scalars are sums of 5e7 random-sign terms: different (equally valid) fp32
+        # summation orders differ by ~sqrt(N)*6e-8 of the sum of magnitudes
+        tol = 2e-3 if i in (3, 4) else 2e-5
+        assert (s - g1[i]).abs().max() <= tol * max(1.0, float(g1[i].abs().max())), i
     assert torch.allclose(torch.cat([parts[0][0], parts[1][0]], 1), g1[0], atol=1e-6, rtol=0)
     # against the generic path
     gg = _bwd(G, x, hs, zs, cs, P, h0, flags=FORCE_GENERIC)
-    for a, b in zip(g1, gg):
+    for i, (a, b) in enumerate(zip(g1, gg)):
         if a.numel():
-            assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))
+            tol = 2e-3 if i in (3, 4) else 2e-5
+            assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())), i
 
 
 def test_lowrank_config4_shape_vs_oracle_sample():
