@@ -29,7 +29,13 @@ FLOPS_BWD = 2 * FLOPS_FWD                        # 8 110 080
 BYTES_FWD = 4 * T * (F + H)                      # 63 360: read x, write hs
 BYTES_BWD = 4 * T * (2 * H + 2 * F)              # 126 720: read grad_hs, hs, x; write d_x
 PEAK_F32_TFLOPS = 157.3                          # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0                        # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0                            # spec; ~6300 achievable
+# bytes per utterance the autograd path actually moves when it saves ONE auxiliary tensor
+# (kernel path 2): fwd reads x, writes hs + pre; bwd reads grad_hs, hs, pre, x (twice: row
+# and transposed-plane producers read the same lines), writes d_x
+BYTES_FWD_PREACT = 4 * T * (F + 2 * H)
+BYTES_BWD_PREACT = 4 * T * (3 * H + 2 * F)
 
 
 def main():
@@ -104,23 +110,40 @@ def main():
         path_b = fastgrnn_cuda.kernel_path(T, B, F, H, direction=1)
         tf_b = B * FLOPS_BWD / (avg_b * 1e-3) / 1e12
         tf_f = B * FLOPS_FWD / (avg_f * 1e-3) / 1e12
+        split = path_b == 2
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("backward_unroll_bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "utterances/sec fwd+bwd, T=99 feat=32 hidden=128, bs=4096 at 1/2/4/8 GPUs",
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FastGRNN dense fwd+bwd training step, T=99 F=32 H=128 B=%d per GPU, fp32, "
-                                   "dense grad_hs, z_s/h_prime_s saved as the reference operator does" % B,
+            "vs_baseline": None, "dtype": "f32 (3xbf16 split MFMA, fp32 accumulate)" if fastgrnn_cuda.kernel_path(T, B, F, H, direction=1) == 2 else "f32", "data": "synthetic",
+            "config": {"workload": "FastGRNN dense fwd+bwd training step (FastGRNNCUDA module + autograd), T=99 F=32 "
+                                   "H=128 B=%d per GPU, fp32 results, dense grad_hs; %s" % (
+                                       B, "3xbf16 split-precision MFMA kernels, one saved [T,B,H] tensor" if split
+                                       else "z_s/h_prime_s saved as the reference operator does"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernel_path": {"forward": path_f, "backward": path_b}},
             # dominant kernel = the backward scan (fastgrnn_hip_backward_unroll); the scan's
             # binding roof at fp32 is the f32 MFMA/FMA rate (intensity ~64 flop/B)
+            # dominant kernel = the backward scan (fastgrnn_hip_backward_unroll).  Its algorithmic work is
+            # fp32: achieved = algorithmic fp32 FLOP / launch time against the fp32 MFMA (= fp32 vector)
+            # peak.  On kernel path 2 every fp32 product is executed as 6 bf16 MFMA terms on the bf16
+            # matrix pipe; "executed" prices those against the dense bf16 peak.
             "roofline": {"kernel": "backward_unroll", "bound": "mfma", "achieved": tf_b, "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf_b / PEAK_F32_TFLOPS, "traffic": None,
-                         "avg_launch_ms": avg_b, "flops_per_launch": B * FLOPS_BWD},
+                         "unit": "TFLOP/s", "frac": tf_b / PEAK_F32_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_b, "flops_per_launch": B * FLOPS_BWD,
+                         "executed": ({"dtype": "bf16 x3 planes, 6 terms", "tflops": 6 * tf_b,
+                                       "peak": PEAK_BF16_TFLOPS, "frac": 6 * tf_b / PEAK_BF16_TFLOPS} if split else None)},
             "roofline_hbm": {"kernel": "backward_unroll", "bound": "hbm",
                              "achieved": B * BYTES_BWD / (avg_b * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None},
+                             "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                             "moved_gbs": (B * BYTES_BWD_PREACT / (avg_b * 1e-3) / 1e9) if split else None},
             "forward_kernel": {"avg_launch_ms": avg_f, "tflops": tf_f, "frac_f32_peak": tf_f / PEAK_F32_TFLOPS,
                                "hbm_gbs": B * BYTES_FWD / (avg_f * 1e-3) / 1e9},
         }

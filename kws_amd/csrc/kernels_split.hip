@@ -292,25 +292,18 @@ struct BwdSplitLds {
 };
 constexpr int OFF_DP = 0, OFF_HP = 3 * PLANE_H, OFF_XP = 6 * PLANE_H;
 
-// One transposed half fragment (4 bf16: utterances +0..3 of this lane's 4-row block, one unit
-// column) per ds_read_b64_tr_b16; EXEC is all ones everywhere these are used.  hipcc does not count
-// asm loads in its lgkmcnt bookkeeping: every consumer sits behind tr_wait(), which names the
-// destinations.
-template <int OFF, int ROWB>
-__device__ __forceinline__ void tr_read2(unsigned long long& lo, unsigned long long& hi, unsigned base) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-               : "=v"(lo), "=v"(hi)
-               : "v"(base), "i"(OFF), "i"(OFF + 4 * ROWB)
-               : "memory");
-}
-__device__ __forceinline__ void tr_wait(unsigned long long (&lo)[3], unsigned long long (&hi)[3]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2])::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ u32x4 join(unsigned long long lo, unsigned long long hi) {
-  return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+// One transposed fragment (8 bf16: utterances +0..7 of this lane's 8-row block, one unit column) =
+// two ds_read_b64_tr_b16 (rows +0..3, +4..7), through the compiler builtin so that hipcc tracks
+// their lgkmcnt and registers itself.  EXEC is all ones wherever this is used (the transpose
+// gathers across the 16 lanes of a group).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ u32x4 tr_frag(unsigned lds_byte_addr, int rowb) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((size_t)lds_byte_addr));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((size_t)(lds_byte_addr + 4 * rowb)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(u32x4, v);
 }
 
 // Reverse scan, pipelined like bwd_scan_mfma (kernels_mfma.hip).  Iteration t:
@@ -424,40 +417,38 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     r.lo = ld4(xp); r.hi = ld4(xp + 4);
   };
 
-  // EW(t): .cu:107-117, in pieces that the caller drops between batches of independent MFMAs so
-  // that the VALU works while the matrix pipe does.  Consumes dh = d_old_h from chain(t+1); leaves
-  // dh = z*g (C-in of chain(t)); publishes the planes of d_pre_t, h_{t-1}, x_t in image buffer
-  // [t&3]; returns the planes of d_pre_t.
-  struct EwState { f32x4 dpv[MT], hpv[MT]; };
-  auto ew_elem = [&](int k, const EwOps& e, EwState& st) __attribute__((always_inline)) {   // element k = 0..7
-    const int mt = k >> 2, r = k & 3;
-    float z, c;
-    if (PREACT) {
-      z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
-      c = ftanh(e.a0[mt][r] + bhv[mt][r]);
-    } else {
-      z = e.a0[mt][r]; c = e.a1[mt][r];
-    }
-    const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
-    float hv = e.h[mt][r];
-    float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
-    float dzp = (hv - sz * c) * gate_dact<GATE>(z) * gg;                     // .cu:110
-    float zg = z * gg;                                                        // .cu:108
-    float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
-    if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; hv = 0.f; }
-    sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
-    st.dpv[mt][r] = dzp + dcp;                                                // .cu:113
-    st.hpv[mt][r] = hv;
-    dh[mt][r] = zg;
-  };
-  auto ew_publish_dp = [&](int t, const EwState& st, Frag3& dpo) __attribute__((always_inline)) {
-    dpo = split3(st.dpv[0], st.dpv[1]);
-    unsigned char* im = &S.img[t & 3][0];
+  // EW(t): .cu:107-117, split by dependence so that the VALU always has work beside the matrix pipe:
+  //   ew_pre   everything that does not need d_old_h: z, c (recomputed from the pre-activation when
+  //            PREACT) and the per-element factors of the derivative formulas; runs under chain(t+1)
+  //   ew_hx    planes of h_{t-1} and x_t into image buffer [t&3]; also under the chain
+  //   ew_post  gg = grad + d_old_h and the products with the factors (slices between the dW/dU tiles)
+  //   ew_publish_dp  planes of d_pre_t into the image buffer and into registers (for d_x)
+  // Leaves dh = z*g, the C-in of chain(t).
+  struct EwPre { f32x4 kc[MT], kz[MT], z[MT], tzc[MT], c[MT]; };
+  struct EwState { f32x4 dpv[MT]; };
+  auto ew_pre = [&](const EwOps& e, EwPre& f, f32x4 (&hpv)[MT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(im + OFF_DP + p * PLANE_H + my_row_h) = dpo.p[p];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float z, c;
+        if (PREACT) {
+          z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
+          c = ftanh(e.a0[mt][r] + bhv[mt][r]);
+        } else {
+          z = e.a0[mt][r]; c = e.a1[mt][r];
+        }
+        float hv = e.h[mt][r];
+        float kc = (sz * (1.0f - z) + sn) * (1.0f - c * c);       // d_pre_c = kc * gg   (.cu:109)
+        float kz = (hv - sz * c) * gate_dact<GATE>(z);            // d_pre_z = kz * gg   (.cu:110)
+        float tzc = (1.0f - z) * c;                               // d_zeta term          (.cu:114)
+        if (RAGGED && !valid) { kc = 0.f; kz = 0.f; z = 0.f; tzc = 0.f; c = 0.f; hv = 0.f; }
+        f.kc[mt][r] = kc; f.kz[mt][r] = kz; f.z[mt][r] = z; f.tzc[mt][r] = tzc; f.c[mt][r] = c;
+        hpv[mt][r] = hv;
+      }
   };
-  auto ew_publish_hx = [&](int t, const EwState& st, const XRaw& xr) __attribute__((always_inline)) {
-    const Frag3 hf = split3(st.hpv[0], st.hpv[1]);
+  auto ew_hx = [&](int t, const f32x4 (&hpv)[MT], const XRaw& xr) __attribute__((always_inline)) {
+    const Frag3 hf = split3(hpv[0], hpv[1]);
     const Frag3 xf = split3(xr.lo, xr.hi);
     unsigned char* im = &S.img[t & 3][0];
 #pragma unroll
@@ -465,6 +456,21 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
       *reinterpret_cast<u32x4*>(im + OFF_HP + p * PLANE_H + my_row_h) = hf.p[p];
       *reinterpret_cast<u32x4*>(im + OFF_XP + p * PLANE_X + my_row_x) = xf.p[p];
     }
+  };
+  auto ew_post = [&](int k, const EwOps& e, const EwPre& f, EwState& st) __attribute__((always_inline)) {   // element k = 0..7
+    const int mt = k >> 2, r = k & 3;
+    const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
+    const float dcp = f.kc[mt][r] * gg, dzp = f.kz[mt][r] * gg;
+    sbz[mt][r] += dzp; sbh[mt][r] += dcp;
+    pz += f.tzc[mt][r] * gg; pn += f.c[mt][r] * gg;                          // .cu:114-115
+    st.dpv[mt][r] = dzp + dcp;                                                // .cu:113
+    dh[mt][r] = f.z[mt][r] * gg;                                              // .cu:108
+  };
+  auto ew_publish_dp = [&](int t, const EwState& st, Frag3& dpo) __attribute__((always_inline)) {
+    dpo = split3(st.dpv[0], st.dpv[1]);
+    unsigned char* im = &S.img[t & 3][0];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(im + OFF_DP + p * PLANE_H + my_row_h) = dpo.p[p];
   };
   // d_x partial of step t over this wave's units (.cu:538): register operands only
   auto dx_partial = [&](int t, const Frag3& dpo) __attribute__((always_inline)) {
@@ -487,50 +493,31 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     // lane groups 0,1 read step sU's images, groups 2,3 step sU-1's
     const unsigned im = lds_img + (unsigned)(((g < 2) ? sU : sU - 1) & 3) * IMG;
     const unsigned trA = im + trA_off, trH = im + trH_off, trX = im + trX_off;
-    unsigned long long alo[MT][3], ahi[MT][3], blo[2][3], bhi[2][3];
-    static_for<MT>([&](auto A2) {
-      static_for<3>([&](auto P) {
-        constexpr int a2 = decltype(A2)::value, pl = decltype(P)::value;
-        tr_read2<pl * PLANE_H + a2 * 32, ROW_H>(alo[a2][pl], ahi[a2][pl], trA);
-      });
-    });
-    auto issue = [&](auto CT, unsigned long long (&lo)[3], unsigned long long (&hi)[3]) __attribute__((always_inline)) {
-      constexpr int ct = decltype(CT)::value;
-      static_for<3>([&](auto P) {
-        constexpr int pl = decltype(P)::value;
-        if constexpr (ct < NFT) tr_read2<pl * PLANE_X + ct * 32, ROW_X>(lo[pl], hi[pl], trX);
-        else tr_read2<pl * PLANE_H + (ct - NFT) * 32, ROW_H>(lo[pl], hi[pl], trH);
-      });
-    };
-    issue(std::integral_constant<int, C0>{}, blo[0], bhi[0]);
-    tr_wait(alo[0], ahi[0]);
-    tr_wait(alo[1], ahi[1]);
-    tr_wait(blo[0], bhi[0]);
     Frag3 Af[MT];
 #pragma unroll
     for (int a2 = 0; a2 < MT; ++a2)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) Af[a2].p[pl] = join(alo[a2][pl], ahi[a2][pl]);
-    static_for<5>([&](auto J) {
-      constexpr int j = decltype(J)::value, ct = C0 + j, cur = j & 1;
-      if constexpr (j + 1 < 5) issue(std::integral_constant<int, ct + 1>{}, blo[cur ^ 1], bhi[cur ^ 1]);
-      Frag3 Bf;
+      for (int pl = 0; pl < 3; ++pl) Af[a2].p[pl] = tr_frag(trA + pl * PLANE_H + a2 * 32, ROW_H);
+    auto load_b = [&](int ct, Frag3& bf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) Bf.p[pl] = join(blo[cur][pl], bhi[cur][pl]);
+      for (int pl = 0; pl < 3; ++pl)
+        bf.p[pl] = (ct < NFT) ? tr_frag(trX + pl * PLANE_X + ct * 32, ROW_X)
+                              : tr_frag(trH + pl * PLANE_H + (ct - NFT) * 32, ROW_H);
+    };
+    Frag3 Bf[2];
+    load_b(C0, Bf[0]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int ct = C0 + j;
+      if (j + 1 < 5) load_b(ct + 1, Bf[(j + 1) & 1]);          // one column tile ahead
 #pragma unroll
       for (int a2 = 0; a2 < MT; ++a2) {
-        if constexpr (ct < NFT) accW[a2][ct] = mfma6(Af[a2], Bf, accW[a2][ct]);
-        else accU[a2][ct - NFT] = mfma6(Af[a2], Bf, accU[a2][ct - NFT]);
+        if (ct < NFT) accW[a2][ct] = mfma6(Af[a2], Bf[j & 1], accW[a2][ct]);
+        else accU[a2][ct - NFT] = mfma6(Af[a2], Bf[j & 1], accU[a2][ct - NFT]);
       }
-      between(J);
-      // in-order issue: a VALU slice only overlaps the matrix pipe if it sits BETWEEN the MFMAs
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
-      }
-      if constexpr (j + 1 < 5) tr_wait(blo[cur ^ 1], bhi[cur ^ 1]);
-    });
+      between(j);                                              // a slice of VALU work beside these MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   // One pipelined iteration (see the header).  dpo holds the planes of d_pre_{t+1} on entry and
@@ -558,23 +545,29 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
       load_xraw(t >= 2 ? t - 2 : 0, x_load);
       load_ew(t >= 2 ? t - 2 : 0, e_load);
     }
-    // ---- d_h chain (.cu:537): C-in = z*g --------------------------------------------------
+    // ---- d_h chain (.cu:537): C-in = z*g; the VALU meanwhile prepares what EW(t-1) can know
+    //      without d_old_h and publishes the planes of h_{t-2}, x_{t-1}
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma6(UTf[mt][s], dB[s], dh[mt]);
+    EwPre fpre;
+    if constexpr (!LAST) {
+      f32x4 hpv[MT];
+      ew_pre(eo, fpre, hpv);
+      ew_hx(t - 1, hpv, xr);
+    }
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
     if (t + 2 < Tn) finish_dx(t + 2);               // published at the top of the previous iteration
     SPLIT_STAMP(2)
-    // five column tiles x 12 independent MFMAs on the matrix pipe; between them the VALU prepares
-    // step t-1: two pieces per tile (8 elements, then the two plane publishes)
+    // five column tiles x 12 independent MFMAs on the matrix pipe; between them the VALU finishes
+    // EW(t-1): two elements per tile, then the d_pre planes
     EwState st;
-    auto pieces = [&](auto J) __attribute__((always_inline)) {
-      constexpr int j = decltype(J)::value;
-      if constexpr (!LAST) {
-        if constexpr (j < 4) { ew_elem(2 * j, eo, st); ew_elem(2 * j + 1, eo, st); }
-        else { ew_publish_dp(t - 1, st, dpo); ew_publish_hx(t - 1, st, xr); }
+    auto pieces = [&](int j) __attribute__((always_inline)) {
+      if (!LAST) {
+        if (j < 4) { ew_post(2 * j, eo, fpre, st); ew_post(2 * j + 1, eo, fpre, st); }
+        else ew_publish_dp(t - 1, st, dpo);
       }
     };
     const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
@@ -582,7 +575,10 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
       weight_grads(std::integral_constant<int, 0>{}, t + 1, pieces);            // pair (t+1, t), tiles 0..4
     } else {
       if (t + 2 <= top) weight_grads(std::integral_constant<int, 1>{}, t + 2, pieces);   // pair (t+2, t+1), tiles 5..9
-      else { static_for<5>(pieces); }
+      else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pieces(j);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(3)
@@ -595,18 +591,22 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   XRaw xE, xO;
   {
     EwState st;
+    EwPre f;
+    f32x4 hpv[MT];
     if ((Tn - 1) & 1) {
       load_ew(Tn - 1, eO); load_xraw(Tn - 1, xO);
       if (Tn >= 2) { load_ew(Tn - 2, eE); load_xraw(Tn - 2, xE); }
+      ew_pre(eO, f, hpv); ew_hx(Tn - 1, hpv, xO);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) ew_elem(k, eO, st);
-      ew_publish_dp(Tn - 1, st, dpoO); ew_publish_hx(Tn - 1, st, xO);
+      for (int k = 0; k < 8; ++k) ew_post(k, eO, f, st);
+      ew_publish_dp(Tn - 1, st, dpoO);
     } else {
       load_ew(Tn - 1, eE); load_xraw(Tn - 1, xE);
       if (Tn >= 2) { load_ew(Tn - 2, eO); load_xraw(Tn - 2, xO); }
+      ew_pre(eE, f, hpv); ew_hx(Tn - 1, hpv, xE);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) ew_elem(k, eE, st);
-      ew_publish_dp(Tn - 1, st, dpoE); ew_publish_hx(Tn - 1, st, xE);
+      for (int k = 0; k < 8; ++k) ew_post(k, eE, f, st);
+      ew_publish_dp(Tn - 1, st, dpoE);
     }
   }
   __syncthreads();              // also orders the zeroed virtual-step images
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
 #endif
   dx_partial(0, dpoE);
-  weight_grads(std::integral_constant<int, 1>{}, 1, [&](auto) __attribute__((always_inline)) {});   // pair (1, 0), tiles 5..9
+  weight_grads(std::integral_constant<int, 1>{}, 1, [&](int) __attribute__((always_inline)) {});   // pair (1, 0), tiles 5..9
   if (1 < Tn) finish_dx(1);
   lds_barrier();
   finish_dx(0);
