@@ -10,7 +10,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("bwd_scan_mfma", "fwd_scan_mfma", "reduce_slabs", "fwd_scan_generic", "bwd_scan_generic"):
+    for k in ("bwd_scan_split", "fwd_scan_split", "reduce_slabs_split", "bwd_scan_mfma", "fwd_scan_mfma",
+              "reduce_slabs", "fwd_scan_generic", "bwd_scan_generic"):
         if k in name:
             return k
     return None
