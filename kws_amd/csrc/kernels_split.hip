@@ -57,6 +57,21 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+#ifdef FASTGRNN_DIAG_STAMPS
+// Diagnostic build only (tools/diag_split.hip): per-segment cycle sums of each wave of block 7.
+__device__ unsigned long long g_sdiag[4][8];
+#define SPLIT_STAMP(idx)                                                                  \
+  {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long now_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    dsum[idx] += now_ - dlast; dlast = now_;                                              \
+  }
+#else
+#define SPLIT_STAMP(idx)
+#endif
+
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                  0, 0);
@@ -176,6 +191,10 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
   };
 
   // One step; xuse = features of frame t (requested a step ago), xload <- frame t+1.
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   auto step = [&](auto first_tag, int t, int cur, Feat& xuse, Feat& xload, Gates& gprev,
                   Gates& gout) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -186,45 +205,60 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int p = 0; p < 3; ++p) hB[s].p[p] = hl[cur][p][(s * 4 + g) * 16 + i];
-    // W.x_t: independent of h, covers the LDS round trip
+    // The two row tiles run one after the other: tile 0's VALU epilogue then sits under tile 1's MFMA
+    // chain (the bf16 matrix pipe overlaps with the VALU).  W.x_t goes first in each tile: it does not
+    // depend on h, so it (and the x split) covers the LDS round trip of the state planes.
     const Frag3 xB = split3(xuse.lo, xuse.hi);
-    f32x4 acc[MT];
+    auto tile_chain = [&](int mt) __attribute__((always_inline)) {
+      f32x4 a = mfma6(Wf[mt], xB, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma6(Wf[mt], xB, f32x4{0.f, 0.f, 0.f, 0.f});
-    __builtin_amdgcn_sched_barrier(0);
-    if (!FIRST) store_step(t - 1, gprev);
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma6(Uf[mt][s], hB[s], acc[mt]);          // .cu:368
-    if (!FIRST) {
-      // spread the store instructions of step t-1 evenly under the chain's 48 MFMAs
-      constexpr int NST = (AUX == 1 ? 3 : AUX == 2 ? 2 : 1) * MT, NM = KS * MT * 6, PER = NM / (NST + 1);
-#pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);     // VMEM write
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NM - NST * PER, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // epilogue (.cu:55-58)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+      for (int s = 0; s < KS; ++s) a = mfma6(Uf[mt][s], hB[s], a);                        // .cu:368
+      return a;
+    };
+    auto tile_epilogue = [&](int mt, const f32x4 a) __attribute__((always_inline)) {     // .cu:55-58
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pre = acc[mt][r];
+        const float pre = a[r];
         const float z = gate_act<GATE>(pre + bzv[mt][r]);
         const float c = ftanh(pre + bhv[mt][r]);
         hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
         gout.z[mt][r] = (AUX == 2) ? pre : z; gout.c[mt][r] = c;
       }
+    };
+    constexpr int NM = (KS + 1) * 6;                 // MFMAs per tile chain
+    SPLIT_STAMP(0)
+    // ---- tile 0 chain; the global stores of step t-1 (they still read h_{t-1}) spread beneath it
+    if (!FIRST) store_step(t - 1, gprev);
+    const f32x4 acc0 = tile_chain(0);
+    if (!FIRST) {
+      constexpr int NST = (AUX == 1 ? 3 : AUX == 2 ? 2 : 1) * MT, PER = NM / (NST + 1);
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);     // VMEM write
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
+    // ---- tile 1 chain || tile 0 epilogue
+    const f32x4 acc1 = tile_chain(1);
+    tile_epilogue(0, acc0);
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);       // VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(2)
+    // ---- tile 1 epilogue, planes of h_t
+    tile_epilogue(1, acc1);
     const Frag3 f = split3(hown[0], hown[1]);
 #pragma unroll
     for (int p = 0; p < 3; ++p) hl[cur ^ 1][p][myfrag] = f.p[p];
     __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(3)
     lds_barrier();
+    SPLIT_STAMP(4)
   };
 
   Feat xa, xb;
@@ -243,25 +277,15 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
   } else {
     store_step(Tn - 1, ga);
   }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // backward  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
-#ifdef FASTGRNN_DIAG_STAMPS
-// Diagnostic build only (tools/diag_split.hip): per-segment cycle sums of each wave of block 7.
-__device__ unsigned long long g_sdiag[4][8];
-#define SPLIT_STAMP(idx)                                                                  \
-  {                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    unsigned long long now_;                                                              \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    dsum[idx] += now_ - dlast; dlast = now_;                                              \
-  }
-#else
-#define SPLIT_STAMP(idx)
-#endif
+
 template <typename Fn, int... Is>
 __device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
