@@ -562,7 +562,6 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         dB[s].p[p] = *reinterpret_cast<const u32x4*>(im + OFF_DP + p * PLANE_H + i * ROW_H + (32 * s + 8 * g) * 2);
-    if (t + 1 < Tn) dx_partial(t + 1, dpo);          // register-only MFMAs cover the LDS round trip
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(0)
     if (!LAST) {
@@ -583,7 +582,10 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     }
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
-    if (t + 2 < Tn) finish_dx(t + 2);               // published at the top of the previous iteration
+    if (t + 2 < Tn) finish_dx(t + 2);               // published in the previous iteration
+    // d_x(t+1): register-only MFMAs, matrix-pipe filler for the VALU-bound region below (must read dpo
+    // before the last slice overwrites it with the planes of d_pre_{t-1})
+    if (t + 1 < Tn) dx_partial(t + 1, dpo);
     SPLIT_STAMP(2)
     // five column tiles x 12 independent MFMAs on the matrix pipe; between them the VALU finishes
     // EW(t-1): two elements per tile, then the d_pre planes
