@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
     if (t + 2 < Tn) finish_dx(t + 2);               // published in the previous iteration
+    SPLIT_STAMP(5)
     // d_x(t+1): register-only MFMAs, matrix-pipe filler for the VALU-bound region below (must read dpo
     // before the last slice overwrites it with the planes of d_pre_{t-1})
     if (t + 1 < Tn) dx_partial(t + 1, dpo);

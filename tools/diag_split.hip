@@ -36,12 +36,12 @@ void run_bwd(int T, int B) {
   printf("bwd_scan_split PREACT=%d: %.1f us (%.2f us/step)\n", (int)PREACT, ts[ts.size() / 2] * 1e3, ts[ts.size() / 2] * 1e3 / T);
   unsigned long long h[4][8];
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sdiag), sizeof(h));
-  const char* names[5] = {"LDS B reads + d_x MFMA", "requests + chain", "finish_dx", "pair dW/dU MFMA || EW pieces", "barrier"};
+  const char* names[6] = {"LDS B reads", "requests + chain || ew_pre, ew_hx", "d_x MFMA", "pair dW/dU MFMA || EW pieces", "barrier", "finish_dx"};
   for (int wv = 0; wv < 4; ++wv) {
     unsigned long long tot = 0;
-    for (int k = 0; k < 5; ++k) tot += h[wv][k];
+    for (int k = 0; k < 6; ++k) tot += h[wv][k];
     printf("   wave %d: %.0f cycles/step:", wv, (double)tot / T);
-    for (int k = 0; k < 5; ++k) printf("  [%s] %.0f", names[k], (double)h[wv][k] / T);
+    for (int k = 0; k < 6; ++k) printf("  [%s] %.0f", names[k], (double)h[wv][k] / T);
     printf("\n");
   }
 }
