@@ -283,6 +283,151 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, low-rank  (H = 256, F = 32, wRank = uRank = 16: BASELINE config 4)
+// ------------------------------------------------------------------------------------------
+// pre = W2 (W1 x) + U2 (U1 h), evaluated factorised like the CPU cell (rnn.py:280-287).  Workgroup =
+// 4 waves = 16 utterances; wave w owns hidden units 64w..64w+63 (four 16-row tiles) and a lane its
+// 16 consecutive units n0..n0+15.  All factor planes are resident in registers.
+//   A  m_h partial: U1 contracted over the wave's OWN 64 units -- the B operand is the lane's own
+//      two fragments of h, straight from registers (h never goes through LDS); m_x = W1 x.
+//   -  the four partials (and m_x, from wave 0) meet in a 16 KB LDS buffer: ONE barrier per step
+//   B  pre tile = [U2 | W2] . [m_h ; m_x]: K = 16 + 16 = one K-step of 32, four row tiles per wave,
+//      run one after the other so that each tile's epilogue sits under the next tile's MFMAs.
+template <int GATE, int AUX, bool RAGGED>
+__global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
+    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ u1, const float* __restrict__ u2,
+    const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs) {
+  constexpr int H = 256, F = 32, R = 16, NT = 4, MROW = 36;   // MROW: padded floats per (wave, utterance) row of m
+  __shared__ __attribute__((aligned(16))) float mp[2][4][16][MROW];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 64 + g * 16;                 // this lane's 16 hidden units
+
+  // ---- resident A operands -----------------------------------------------------------------
+  Frag3 U1f[2], W1f, UW2f[NT];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {                    // rows = rank index i; K-step v = units n0' + 8v + j of lane group g
+    const float* p = u1 + (size_t)i * H + wv * 64 + g * 16 + 8 * v;
+    U1f[v] = split3(ld4(p), ld4(p + 4));
+  }
+  {
+    const float* p = w1 + (size_t)i * F + 8 * g;
+    W1f = split3(ld4(p), ld4(p + 4));
+  }
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {                // rows = units; K = [m_h rows 8g.. | m_x rows 8(g-2)..]
+    const int nA = wv * 64 + (i >> 2) * 16 + mt * 4 + (i & 3);
+    const float* p = (g < 2) ? u2 + (size_t)nA * R + 8 * g : w2 + (size_t)nA * R + 8 * (g - 2);
+    UW2f[mt] = split3(ld4(p), ld4(p + 4));
+  }
+  f32x4 bzv[NT], bhv[NT], hown[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    bzv[mt] = ld4(bz + n0 + 4 * mt);
+    bhv[mt] = ld4(bh + n0 + 4 * mt);
+    hown[mt] = ld4(h0 + (size_t)bc * H + n0 + 4 * mt);
+  }
+  Frag3 hfrag[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+
+  struct Feat { f32x4 lo, hi; };
+  struct Gates { f32x4 z[NT], c[NT]; };
+  auto load_x = [&](int t, Feat& q) __attribute__((always_inline)) {
+    const float* xp = x + ((size_t)t * B + bc) * F + 8 * g;
+    q.lo = ld4(xp); q.hi = ld4(xp + 4);
+  };
+  auto store_step = [&](int t, const Gates& gt) __attribute__((always_inline)) {   // hown still holds h_t
+    if (valid) {
+      const size_t o = ((size_t)t * B + b) * H + n0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
+      if (AUX == 1) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
+      }
+    }
+  };
+
+  auto step = [&](auto first_tag, int t, int cur, Feat& xuse, Feat& xload, Gates& gprev,
+                  Gates& gout) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    load_x(t + 1 < Tn ? t + 1 : t, xload);
+    // ---- A: rank-space partials ------------------------------------------------------------
+    const Frag3 xB = split3(xuse.lo, xuse.hi);
+    f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});
+    mh = mfma6(U1f[1], hfrag[1], mh);                                                   // rnn.py:286 (partial over own units)
+    f32x4 mx = mfma6(W1f, xB, f32x4{0.f, 0.f, 0.f, 0.f});                               // rnn.py:280
+    if (wv != 0) mx = f32x4{0.f, 0.f, 0.f, 0.f};                                        // m_x enters the sum once
+    if (!FIRST) store_step(t - 1, gprev);
+    // lane (b=i, g) holds rows 4g..4g+3 of both 16-row results
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
+    lds_barrier();
+    // ---- m = sum of the partials; this lane's B fragment is rows 8g..8g+7 of [m_h ; m_x] -------
+    f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
+#pragma unroll
+    for (int w2i = 0; w2i < 4; ++w2i) {
+      mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
+      mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
+    }
+    const Frag3 mB = split3(mlo, mhi);
+    // ---- B: pre-activation tiles, epilogue of tile k under the MFMAs of tile k+1 -----------------
+    f32x4 acc[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      acc[mt] = mfma6(UW2f[mt], mB, f32x4{0.f, 0.f, 0.f, 0.f});                          // rnn.py:281,287,289
+      if (mt > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                                    // .cu:55-58, tile mt-1
+          const float pre = acc[mt - 1][r];
+          const float z = gate_act<GATE>(pre + bzv[mt - 1][r]);
+          const float c = ftanh(pre + bhv[mt - 1][r]);
+          hown[mt - 1][r] = (sz * (1.0f - z) + sn) * c + hown[mt - 1][r] * z;
+          gout.z[mt - 1][r] = z; gout.c[mt - 1][r] = c;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pre = acc[NT - 1][r];
+      const float z = gate_act<GATE>(pre + bzv[NT - 1][r]);
+      const float c = ftanh(pre + bhv[NT - 1][r]);
+      hown[NT - 1][r] = (sz * (1.0f - z) + sn) * c + hown[NT - 1][r] * z;
+      gout.z[NT - 1][r] = z; gout.c[NT - 1][r] = c;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
+  };
+
+  Feat xa, xb;
+  Gates ga, gb;
+  load_x(0, xa);
+  step(std::true_type{}, 0, 0, xa, xb, gb, ga);
+  int t = 1;
+  for (; t + 1 < Tn; t += 2) {
+    step(std::false_type{}, t, 1, xb, xa, ga, gb);
+    step(std::false_type{}, t + 1, 0, xa, xb, gb, ga);
+  }
+  if (t < Tn) {
+    step(std::false_type{}, t, 1, xb, xa, ga, gb);
+    store_step(Tn - 1, gb);
+  } else {
+    store_step(Tn - 1, ga);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
 
@@ -777,10 +922,32 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   else               { if (ragged) go(fwd_scan_split<GATE, 0, true>); else go(fwd_scan_split<GATE, 0, false>); }
 }
 
+template <int GATE>
+void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
+                             void* zs, void* cs, hipStream_t s) {
+  dim3 grid((d.B + 15) / 16), block(256);
+  const bool ragged = (d.B % 16) != 0;
+  auto go = [&](auto kern) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w1,
+                       (const float*)p.w2, (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate,
+                       (const float*)p.bias_update, (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs,
+                       (float*)cs);
+  };
+  if (zs) { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true>); else go(fwd_scan_lowrank_split<GATE, 1, false>); }
+  else    { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true>); else go(fwd_scan_lowrank_split<GATE, 0, false>); }
+}
+
+bool lowrank_fwd_shape(const fastgrnn_desc& d) {
+  return d.H == 256 && d.F == 32 && d.w_rank == 16 && d.u_rank == 16;
+}
+
 }  // namespace
 
 bool split_supported(const fastgrnn_desc& d, int direction) {
-  (void)direction;
+  if (d.dtype != FASTGRNN_F32 || d.update_nl != FASTGRNN_NL_TANH || d.gate_nl < FASTGRNN_NL_SIGMOID ||
+      d.gate_nl > FASTGRNN_NL_TANH)
+    return false;
+  if (direction == 0 && lowrank_fwd_shape(d)) return true;     // forward only; its backward is the generic scan
   return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
          d.update_nl == FASTGRNN_NL_TANH && d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH &&
          d.H == 128 && d.F == 32;
@@ -802,6 +969,15 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                   void* zs, void* cs, void*, hipStream_t s) {
   if (!(d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
+  if (lowrank_fwd_shape(d)) {
+    if (d.flags & FASTGRNN_FLAG_SAVE_PREACT) return FASTGRNN_ERR_UNSUPPORTED;
+    switch (d.gate_nl) {
+      case FASTGRNN_NL_SIGMOID: launch_fwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
+      case FASTGRNN_NL_RELU: launch_fwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;
+      default: launch_fwd_lowrank_gate<FASTGRNN_NL_TANH>(d, p, x, h0, hs, zs, cs, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
+  }
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_fwd_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
     case FASTGRNN_NL_RELU: launch_fwd_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;
