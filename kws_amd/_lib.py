@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfastgrnn_hip.so")
+# FASTGRNN_HIP_LIB: A/B a differently built library (tools/) without touching the in-tree one
+LIB_PATH = os.environ.get("FASTGRNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libfastgrnn_hip.so")
 
 ABI_VERSION = 1
 

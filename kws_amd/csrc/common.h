@@ -52,6 +52,12 @@ int generic_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                      const void* hs, const void* zs, const void* cs, const void* h0,
                      const fastgrnn_grads& g, void* ws, hipStream_t s);
 
+// C[M,N] = A[:, :M]^T . B[:, :N] over R rows (deterministic split-K); rows of B below shiftB come from
+// B0, the rest from B1.  part: tn_gemm_f32_ws(R, M, N) bytes of workspace.
+size_t tn_gemm_f32_ws(size_t R, int M, int N);
+void tn_gemm_f32(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t shiftB,
+                 int ldb, float* part, float* C, hipStream_t s);
+
 bool mfma_supported(const fastgrnn_desc& d, int direction);
 size_t mfma_forward_ws(const fastgrnn_desc& d);
 size_t mfma_backward_ws(const fastgrnn_desc& d);

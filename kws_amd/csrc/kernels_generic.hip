@@ -279,12 +279,13 @@ __global__ void gemm_rows(size_t M, int N, int K, const T* __restrict__ A0, cons
   C[i] = acc;
 }
 
-// part[s][M,N] = sum_{r in chunk s} A[r][m] * B[r][n];  A:[R,M], B:[R,N] (B with row shift).
+// part[s][M,N] = sum_{r in chunk s} A[r][m] * B[r][n];  A:[R, lda] (first M columns used),
+// B:[R, ldb] (first N columns used; B with row shift).
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_splitk(size_t R, int M, int N, size_t chunk,
-                                                      const T* __restrict__ A,
+                                                      const T* __restrict__ A, int lda,
                                                       const T* __restrict__ B0, const T* __restrict__ B1, size_t shiftB,
-                                                      T* __restrict__ part) {
+                                                      int ldb, T* __restrict__ part) {
   __shared__ T As[16][17];
   __shared__ T Bs[16][17];
   const int tn = (N + 15) / 16;
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256) void gemm_tn_splitk(size_t R, int M, int N, si
   T acc = 0;
   for (size_t r = r0; r < r1; r += 16) {
     size_t rr = r + ty;
-    As[ty][tx] = (rr < r1 && m0 + tx < M) ? A[rr * M + m0 + tx] : T(0);
-    Bs[ty][tx] = (rr < r1 && n0 + tx < N) ? row_ptr<T>(B0, B1, shiftB, rr, N)[n0 + tx] : T(0);
+    As[ty][tx] = (rr < r1 && m0 + tx < M) ? A[rr * lda + m0 + tx] : T(0);
+    Bs[ty][tx] = (rr < r1 && n0 + tx < N) ? row_ptr<T>(B0, B1, shiftB, rr, ldb)[n0 + tx] : T(0);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc += As[k][ty] * Bs[k][tx];
@@ -340,23 +341,82 @@ BwdWs bwd_layout(const fastgrnn_desc& d) {
   return w;
 }
 
+// Same product, LDS-tiled: a workgroup owns 64 rows of A and streams K in chunks of 64; thread
+// (row r = tid&63, column group cg = tid>>6) keeps up to 16 outputs n = cg + 4c in registers.  A
+// chunk reads are coalesced (consecutive threads = consecutive k of one row), the A element of a
+// row is read once per k from LDS (stride-65 rows: conflict-free) and the B row is a wave-wide
+// broadcast.  N <= 64.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_rows_tiled(size_t M, int N, int K, const T* __restrict__ A0,
+                                                       const T* __restrict__ A1, size_t shiftA,
+                                                       const T* __restrict__ Bm, int transB, T* __restrict__ C) {
+  constexpr int TM = 64, KC = 64, NC = 16;
+  __shared__ T As[TM][KC + 1];
+  __shared__ T Bs[KC][64];
+  const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+  const size_t m0 = (size_t)blockIdx.x * TM;
+  T acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    for (int idx = tid; idx < TM * KC; idx += 256) {
+      const int rr = idx / KC, kk = idx % KC;
+      const size_t m = m0 + rr;
+      As[rr][kk] = (m < M && k0 + kk < K) ? row_ptr<T>(A0, A1, shiftA, m, K)[k0 + kk] : T(0);
+    }
+    for (int idx = tid; idx < KC * 64; idx += 256) {
+      const int kk = idx / 64, n = idx % 64;
+      T v = 0;
+      if (n < N && k0 + kk < K) v = transB ? Bm[(size_t)n * K + k0 + kk] : Bm[(size_t)(k0 + kk) * N + n];
+      Bs[kk][n] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < KC; ++kk) {
+      const T a = As[r][kk];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] += a * Bs[kk][cg + 4 * c];
+    }
+    __syncthreads();
+  }
+  const size_t m = m0 + r;
+  if (m < M) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int n = cg + 4 * c;
+      if (n < N) C[m * N + n] = acc[c];
+    }
+  }
+}
+
 template <typename T>
 void launch_rows(size_t M, int N, int K, const T* A0, const T* A1, size_t shiftA, const T* Bm, int transB,
                  T* C, hipStream_t s) {
+  if (N <= 64) {
+    hipLaunchKernelGGL(gemm_rows_tiled<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, M, N, K, A0, A1, shiftA,
+                       Bm, transB, C);
+    return;
+  }
   size_t tot = M * (size_t)N;
   hipLaunchKernelGGL(gemm_rows<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, M, N, K, A0, A1, shiftA, Bm,
                      transB, C);
 }
 
 template <typename T>
-void launch_tn(size_t R, int M, int N, const T* A, const T* B0, const T* B1, size_t shiftB, T* part, T* C,
-               hipStream_t s) {
+void launch_tn_ld(size_t R, int M, int N, const T* A, int lda, const T* B0, const T* B1, size_t shiftB, int ldb,
+                  T* part, T* C, hipStream_t s) {
   int nsplit = (int)((R + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
   int tiles = ((M + 15) / 16) * ((N + 15) / 16);
-  hipLaunchKernelGGL(gemm_tn_splitk<T>, dim3(tiles, nsplit), dim3(256), 0, s, R, M, N, SPLITK_CHUNK, A, B0, B1,
-                     shiftB, part);
+  hipLaunchKernelGGL(gemm_tn_splitk<T>, dim3(tiles, nsplit), dim3(256), 0, s, R, M, N, SPLITK_CHUNK, A, lda, B0, B1,
+                     shiftB, ldb, part);
   size_t MN = (size_t)M * N;
   hipLaunchKernelGGL(reduce_splitk<T>, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, s, nsplit, MN, part, C);
+}
+
+template <typename T>
+void launch_tn(size_t R, int M, int N, const T* A, const T* B0, const T* B1, size_t shiftB, T* part, T* C,
+               hipStream_t s) {
+  launch_tn_ld<T>(R, M, N, A, M, B0, B1, shiftB, N, part, C, s);
 }
 
 template <typename T>
@@ -453,6 +513,14 @@ int generic_backward_t(const fastgrnn_desc& d, const fastgrnn_params& p, const v
 }
 
 }  // namespace
+
+size_t tn_gemm_f32_ws(size_t R, int M, int N) {
+  return align256(((R + SPLITK_CHUNK - 1) / SPLITK_CHUNK) * (size_t)M * N * 4);
+}
+void tn_gemm_f32(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t shiftB,
+                 int ldb, float* part, float* C, hipStream_t s) {
+  launch_tn_ld<float>(R, M, N, A, lda, B0, B1, shiftB, ldb, part, C, s);
+}
 
 size_t generic_forward_ws(const fastgrnn_desc& d) {
   size_t es = d.dtype == FASTGRNN_F64 ? 8 : 4;

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
 
   struct Feat { f32x4 lo, hi; };
-  struct Gates { f32x4 z[NT], c[NT]; };
+  struct Gates { f32x4 z[NT], c[NT], mlo, mhi; };
   auto load_x = [&](int t, Feat& q) __attribute__((always_inline)) {
     const float* xp = x + ((size_t)t * B + bc) * F + 8 * g;
     q.lo = ld4(xp); q.hi = ld4(xp + 4);
@@ -355,6 +355,15 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
       if (AUX == 1) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
+      } else if (AUX == 2) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);      // gt.z carries the pre-activation
+        // [m_h | m_x] of the step: cs is [T,B,32] in this mode; every wave holds the same sum, wave w
+        // stores lane groups g == w (8 floats each)
+        if (g == wv) {
+          float* mo = cs + ((size_t)t * B + b) * 32 + 8 * g;
+          st4(mo, gt.mlo); st4(mo + 4, gt.mhi);
+        }
       }
     }
   };
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
       mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
       mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
     }
+    if (AUX == 2) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
     const Frag3 mB = split3(mlo, mhi);
     // ---- B: pre-activation tiles, epilogue of tile k under the MFMAs of tile k+1 -----------------
     f32x4 acc[NT];
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
           const float z = gate_act<GATE>(pre + bzv[mt - 1][r]);
           const float c = ftanh(pre + bhv[mt - 1][r]);
           hown[mt - 1][r] = (sz * (1.0f - z) + sn) * c + hown[mt - 1][r] * z;
-          gout.z[mt - 1][r] = z; gout.c[mt - 1][r] = c;
+          gout.z[mt - 1][r] = (AUX == 2) ? pre : z; gout.c[mt - 1][r] = c;
         }
       }
     }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
       const float z = gate_act<GATE>(pre + bzv[NT - 1][r]);
       const float c = ftanh(pre + bhv[NT - 1][r]);
       hown[NT - 1][r] = (sz * (1.0f - z) + sn) * c + hown[NT - 1][r] * z;
-      gout.z[NT - 1][r] = z; gout.c[NT - 1][r] = c;
+      gout.z[NT - 1][r] = (AUX == 2) ? pre : z; gout.c[NT - 1][r] = c;
     }
 #pragma unroll
     for (int v = 0; v < 2; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
@@ -906,6 +916,269 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                      (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, low-rank  (H = 256, F = 32, wRank = uRank = 16), FASTGRNN_FLAG_SAVE_PREACT contract only
+// ------------------------------------------------------------------------------------------
+// Mirror of fwd_scan_lowrank_split.  Per step: EW on the VALU (z, c recomputed from the saved
+// pre-activation) -> d_pre; rank-space partial [U2|W2]^T d_pre over the wave's OWN units with the B
+// operand straight from registers; the four partials meet in LDS (one barrier); d_h = z*g + U1^T d_m_h
+// for the wave's own units and d_x = W1^T d_m_x.  d_pre[T,B,H] and d_m[T,B,32] go to the workspace:
+// the weight gradients (K = T*B) are contracted afterwards by split-K GEMMs (.cu:546-555 evaluated
+// factorised), because neither their accumulators nor the images they would need fit on chip beside
+// the factors.
+constexpr int SLAB_LR = 576;   // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded to 64
+
+template <int GATE, bool RAGGED>
+__global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
+    int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ hs, const float* __restrict__ pre_s,
+    const float* __restrict__ h0, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ u1, const float* __restrict__ u2,
+    const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ d_x, float* __restrict__ d_h0,
+    float* __restrict__ dpre_ws, float* __restrict__ dm_ws, float* __restrict__ part) {
+  constexpr int H = 256, F = 32, R = 16, NT = 4, MROW = 36;
+  __shared__ __attribute__((aligned(16))) float mp[2][4][16][MROW];
+  __shared__ __attribute__((aligned(16))) float sbias[2][H];
+  __shared__ float red[8];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 64 + g * 16;
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+  sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid];
+
+  // ---- resident A operands -----------------------------------------------------------------
+  // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units: tile 0 rows = U2 columns, tile 1 = W2 columns
+  Frag3 UW2Tf[2][2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    const float* src = tl == 0 ? u2 : w2;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = src[(size_t)(n0 + 8 * v + j) * R + i];
+        hi[j] = src[(size_t)(n0 + 8 * v + 4 + j) * R + i];
+      }
+      UW2Tf[tl][v] = split3(lo, hi);
+    }
+  }
+  // d_h[k][b] = z*g + sum_j U1[j][k] d_m_h[j][b]: rows = own units, K = [d_m_h rows 8g.. | nothing]
+  Frag3 U1Tf[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    const int kA = wv * 64 + (i >> 2) * 16 + mt * 4 + (i & 3);
+    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (g < 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = u1[(size_t)(8 * g + j) * H + kA];
+        hi[j] = u1[(size_t)(8 * g + 4 + j) * H + kA];
+      }
+    }
+    U1Tf[mt] = split3(lo, hi);
+  }
+  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv&1 (stored by waves 0,1), K = [nothing | d_m_x rows 8(g-2)..]
+  Frag3 W1Tf;
+  {
+    const int f = (wv & 1) * 16 + i;
+    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (g >= 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = w1[(size_t)(8 * (g - 2) + j) * F + f];
+        hi[j] = w1[(size_t)(8 * (g - 2) + 4 + j) * F + f];
+      }
+    }
+    W1Tf = split3(lo, hi);
+  }
+
+  f32x4 sbz[NT], sbh[NT], dh[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
+  float pz = 0.f, pn = 0.f;
+
+  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
+  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    const size_t o = ((size_t)t * B + bc) * H + n0;
+    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)B * H;   // .cu:478-481
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      e.g[mt] = ld4(ghs + o + 4 * mt);
+      e.a0[mt] = ld4(pre_s + o + 4 * mt);
+      e.h[mt] = ld4(hprev + 4 * mt);
+    }
+  };
+
+  auto step = [&](int t, const EwOps& e, EwOps& e_load) __attribute__((always_inline)) {
+    const int cur = t & 1;
+    if (t > 0) load_ew(t - 1, e_load);
+    // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
+    f32x4 dpv[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 4 * mt]);
+      const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 4 * mt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = gate_act<GATE>(e.a0[mt][r] + bzq[r]);
+        const float c = ftanh(e.a0[mt][r] + bhq[r]);
+        const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
+        float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
+        float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;             // .cu:110
+        float zg = z * gg;                                                        // .cu:108
+        float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
+        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; }
+        sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
+        dpv[mt][r] = dzp + dcp;                                                   // .cu:113
+        dh[mt][r] = zg;
+      }
+    }
+    if (valid) {
+      float* o = dpre_ws + ((size_t)t * B + b) * H + n0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) st4(o + 4 * mt, dpv[mt]);
+    }
+    // ---- rank-space partial over own units: B operand = this lane's two fragments of d_pre ----
+    const Frag3 d0 = split3(dpv[0], dpv[1]), d1 = split3(dpv[2], dpv[3]);
+    f32x4 mh = mfma6(UW2Tf[0][0], d0, f32x4{0.f, 0.f, 0.f, 0.f});
+    mh = mfma6(UW2Tf[0][1], d1, mh);
+    f32x4 mx = mfma6(UW2Tf[1][0], d0, f32x4{0.f, 0.f, 0.f, 0.f});
+    mx = mfma6(UW2Tf[1][1], d1, mx);
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
+    lds_barrier();
+    f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
+#pragma unroll
+    for (int w2i = 0; w2i < 4; ++w2i) {
+      mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
+      mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
+    }
+    if (wv == 0 && valid) {                          // [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
+      float* mo = dm_ws + ((size_t)t * B + b) * 32 + 8 * g;
+      st4(mo, mlo); st4(mo + 4, mhi);
+    }
+    const Frag3 mB = split3(mlo, mhi);
+    // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) dh[mt] = mfma6(U1Tf[mt], mB, dh[mt]);
+    const f32x4 dxv = mfma6(W1Tf, mB, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (wv < 2 && valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, dxv);
+  };
+
+  EwOps ea, eb;
+  __syncthreads();                                   // sbias
+  load_ew(Tn - 1, ea);
+  int t = Tn - 1;
+  for (; t >= 1; t -= 2) {
+    step(t, ea, eb);
+    step(t - 1, eb, ea);
+  }
+  if (t == 0) step(0, ea, eb);
+  // ---- flush ---------------------------------------------------------------------------------
+  if (valid) {
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = sbz[mt][r], c = sbh[mt][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
+      if (i == 0) {
+        float* pb = part + (size_t)blockIdx.x * SLAB_LR;
+        pb[n0 + 4 * mt + r] = a;
+        pb[H + n0 + 4 * mt + r] = c;
+      }
+    }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
+  if (l == 0) { red[wv] = pz; red[4 + wv] = pn; }
+  __syncthreads();
+  if (tid == 0) {
+    float* pzn = part + (size_t)blockIdx.x * SLAB_LR + 2 * H;
+    pzn[0] = red[0] + red[1] + red[2] + red[3];
+    pzn[1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// bias / zeta / nu gradients of the low-rank backward: fixed-order sum over workgroups
+__global__ void reduce_lowrank_small(int nwg, const float* __restrict__ part, const float* __restrict__ zeta,
+                                     const float* __restrict__ nu, float* __restrict__ d_bz, float* __restrict__ d_bh,
+                                     float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // 0 .. 2*256+1
+  if (idx >= 2 * 256 + 2) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int wg = 0;
+  for (; wg + 3 < nwg; wg += 4) {
+    a0 += part[(size_t)wg * SLAB_LR + idx]; a1 += part[(size_t)(wg + 1) * SLAB_LR + idx];
+    a2 += part[(size_t)(wg + 2) * SLAB_LR + idx]; a3 += part[(size_t)(wg + 3) * SLAB_LR + idx];
+  }
+  for (; wg < nwg; ++wg) a0 += part[(size_t)wg * SLAB_LR + idx];
+  const float t = (a0 + a1) + (a2 + a3);
+  if (idx < 256) d_bz[idx] = t;
+  else if (idx < 512) d_bh[idx - 256] = t;
+  else if (idx == 512) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }
+  else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }
+}
+
+// C[H,32] -> d_u2[H,16] | d_w2[H,16]
+__global__ void split_cols_16_16(int H, const float* __restrict__ C, float* __restrict__ a, float* __restrict__ b) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * 32) return;
+  const int n = idx >> 5, j = idx & 31;
+  if (j < 16) a[n * 16 + j] = C[idx]; else b[n * 16 + (j - 16)] = C[idx];
+}
+
+struct LowrankBwdWs { size_t dpre, dm, part, tmp, splitk, total; };
+LowrankBwdWs lowrank_bwd_layout(const fastgrnn_desc& d) {
+  const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
+  LowrankBwdWs L; size_t o = 0;
+  L.dpre = o; o += align256(TB * 256 * 4);
+  L.dm = o; o += align256(TB * 32 * 4);
+  L.part = o; o += align256(nwg * SLAB_LR * 4);
+  L.tmp = o; o += align256(256 * 32 * 4);
+  L.splitk = o; o += tn_gemm_f32_ws(TB, 256, 32);      // the largest of the three products (16 x 256 is the same size)
+  L.total = o;
+  return L;
+}
+
+template <int GATE>
+void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
+                             const void* hs, const void* pre_s, const void* m_s, const void* h0,
+                             const fastgrnn_grads& g, void* ws, hipStream_t s) {
+  const LowrankBwdWs L = lowrank_bwd_layout(d);
+  char* base = reinterpret_cast<char*>(ws);
+  float* dpre = (float*)(base + L.dpre); float* dm = (float*)(base + L.dm); float* part = (float*)(base + L.part);
+  float* tmp = (float*)(base + L.tmp); float* splitk = (float*)(base + L.splitk);
+  const int nwg = (d.B + 15) / 16;
+  const size_t TB = (size_t)d.T * d.B;
+  auto go = [&](auto kern) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, s, d.T, d.B, (const float*)ghs, (const float*)hs,
+                       (const float*)pre_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
+                       (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate, (const float*)p.bias_update,
+                       (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, dpre, dm, part);
+  };
+  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true>); else go(bwd_scan_lowrank_split<GATE, false>);
+  hipLaunchKernelGGL(reduce_lowrank_small, dim3(3), dim3(256), 0, s, nwg, part, (const float*)p.zeta,
+                     (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
+                     (float*)g.d_nu);
+  // d_u2 | d_w2 = d_pre^T . [m_h | m_x]     (.cu:546-555, factorised)
+  tn_gemm_f32(TB, 256, 32, dpre, 256, (const float*)m_s, (const float*)m_s, 0, 32, splitk, tmp, s);
+  hipLaunchKernelGGL(split_cols_16_16, dim3(32), dim3(256), 0, s, 256, tmp, (float*)g.d_u2, (float*)g.d_w2);
+  // d_u1 = d_m_h^T . H_prev  (rows of t = 0 are h0, the rest hs[t-1]);  d_w1 = d_m_x^T . X
+  tn_gemm_f32(TB, 16, 256, dm, 32, (const float*)h0, (const float*)hs, (size_t)d.B, 256, splitk, (float*)g.d_u1, s);
+  tn_gemm_f32(TB, 16, 32, dm + 16, 32, (const float*)x, (const float*)x, 0, 32, splitk, (float*)g.d_w1, s);
+}
+
 template <int GATE>
 void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                      void* zs, void* cs, hipStream_t s) {
@@ -933,8 +1206,10 @@ void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                        (const float*)p.bias_update, (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs,
                        (float*)cs);
   };
-  if (zs) { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true>); else go(fwd_scan_lowrank_split<GATE, 1, false>); }
-  else    { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true>); else go(fwd_scan_lowrank_split<GATE, 0, false>); }
+  const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
+  if (aux == 1)      { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true>); else go(fwd_scan_lowrank_split<GATE, 1, false>); }
+  else if (aux == 2) { if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true>); else go(fwd_scan_lowrank_split<GATE, 2, false>); }
+  else               { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true>); else go(fwd_scan_lowrank_split<GATE, 0, false>); }
 }
 
 bool lowrank_fwd_shape(const fastgrnn_desc& d) {
@@ -947,17 +1222,31 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   if (d.dtype != FASTGRNN_F32 || d.update_nl != FASTGRNN_NL_TANH || d.gate_nl < FASTGRNN_NL_SIGMOID ||
       d.gate_nl > FASTGRNN_NL_TANH)
     return false;
-  if (direction == 0 && lowrank_fwd_shape(d)) return true;     // forward only; its backward is the generic scan
+  // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style
+  // backward with z_s / h_prime_s stays on the generic scan)
+  if (lowrank_fwd_shape(d)) return direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
          d.update_nl == FASTGRNN_NL_TANH && d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH &&
          d.H == 128 && d.F == 32;
 }
 
-size_t split_backward_ws(const fastgrnn_desc& d) { return align256((size_t)((d.B + 15) / 16) * SLAB * 4); }
+size_t split_backward_ws(const fastgrnn_desc& d) {
+  if (lowrank_fwd_shape(d)) return lowrank_bwd_layout(d).total;
+  return align256((size_t)((d.B + 15) / 16) * SLAB * 4);
+}
 
 int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                    const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws,
                    hipStream_t s) {
+  if (lowrank_fwd_shape(d)) {
+    if (!cs) return FASTGRNN_ERR_NULL_POINTER;       // the rank-space vector saved by the forward
+    switch (d.gate_nl) {
+      case FASTGRNN_NL_SIGMOID: launch_bwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+      case FASTGRNN_NL_RELU: launch_bwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+      default: launch_bwd_lowrank_gate<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
+  }
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
@@ -970,7 +1259,7 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
                   void* zs, void* cs, void*, hipStream_t s) {
   if (!(d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
   if (lowrank_fwd_shape(d)) {
-    if (d.flags & FASTGRNN_FLAG_SAVE_PREACT) return FASTGRNN_ERR_UNSUPPORTED;
+    if ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (!zs || !cs)) return FASTGRNN_ERR_NULL_POINTER;
     switch (d.gate_nl) {
       case FASTGRNN_NL_SIGMOID: launch_fwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
       case FASTGRNN_NL_RELU: launch_fwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;

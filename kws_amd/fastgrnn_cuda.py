@@ -164,6 +164,9 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         hs = torch.empty(oshape, dtype=input.dtype, device=dev)
         zs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates or preact) else None
         cs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates and not preact) else None
+        if preact and desc.w_rank and desc.u_rank:
+            # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step
+            cs = torch.empty((T, B, desc.w_rank + desc.u_rank), dtype=input.dtype, device=dev)
         nbytes = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))
         ws, wsp = _workspace(nbytes, dev)
         fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
@@ -174,8 +177,8 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         # ws was allocated by torch's caching allocator on this same (current) stream, so
         # its reuse after this function returns is stream-ordered behind the launches above.
         del ws
-    if preact:
-        return [hs, zs]          # zs holds the pre-activation W.x + U.h
+    if preact:                   # zs holds the pre-activation W.x + U.h
+        return [hs, zs] if cs is None else [hs, zs, cs]
     return [hs, zs, cs] if want_gates else [hs]
 
 
@@ -186,7 +189,11 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
     if preact:
         if bias_gate is None or bias_update is None:
             raise RuntimeError("FLAG_SAVE_PREACT backward needs bias_gate and bias_update")
-        h_prime = z              # unused by the kernel; keeps the shape checks below uniform
+        rank_space = h_prime if (_present(w1) and _present(u1)) else None
+        if rank_space is not None:
+            _check_input(rank_space, "rank_space")
+            _expect(rank_space, (input.shape[0], input.shape[1], w1.shape[0] + u1.shape[0]), "rank_space")
+        h_prime = z              # keeps the shape checks below uniform
     for t, n in ((grad_h, "grad_h"), (input, "input"), (hs_or_old_h, "hidden_states" if unrolled else "old_h"),
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
         _check_input(t, n)
@@ -230,7 +237,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         with _Timed("backward", dev):
             if unrolled:
                 st = lib.fastgrnn_hip_backward_unroll(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
-                                                      _ptr(hs_or_old_h), _ptr(z), _ptr(None if preact else h_prime),
+                                                      _ptr(hs_or_old_h), _ptr(z), _ptr(rank_space if preact else h_prime),
                                                       _ptr(h0), C.byref(grads), wsp, nbytes, _stream(dev))
             else:
                 st = lib.fastgrnn_hip_backward(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),

@@ -75,13 +75,16 @@ class FastGRNNUnrollFunction(Function):
         rw = w1.shape[0] if w1.numel() else 0
         ru = u1.shape[0] if u1.numel() else 0
         preact = (input.dtype == torch.float32 and input.is_cuda and
-                  fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1) == 2)
+                  fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
+                                            _lib.FLAG_SAVE_PREACT) == 2)
         flags = _lib.FLAG_SAVE_PREACT if preact else 0
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
                                                gate_non_linearity, w1, w2, u1, u2, flags=flags)
         hidden_states = outputs[0]
         if preact:
-            variables = [input, hidden_states, zeta, nu, w, u, outputs[1], bias_gate, bias_update,
+            # outputs[2] (factorised operands only): the rank-space vector [U1.h | W1.x] per step
+            aux2 = outputs[2] if len(outputs) > 2 else outputs[1]
+            variables = [input, hidden_states, zeta, nu, w, u, outputs[1], aux2, bias_gate, bias_update,
                          old_h, w1, w2, u1, u2]
         else:
             variables = [input, hidden_states, zeta, nu, w, u] + outputs[1:] + [old_h, w1, w2, u1, u2]
@@ -93,10 +96,10 @@ class FastGRNNUnrollFunction(Function):
     @staticmethod
     def backward(ctx, grad_h):
         if ctx.preact:
-            (input, hidden_states, zeta, nu, w, u, pre_s, bias_gate, bias_update, old_h,
+            (input, hidden_states, zeta, nu, w, u, pre_s, aux2, bias_gate, bias_update, old_h,
              w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
-                                                    pre_s, pre_s, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
+                                                    pre_s, aux2, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
                                                     flags=_lib.FLAG_SAVE_PREACT, bias_gate=bias_gate,
                                                     bias_update=bias_update)
         else:

@@ -173,6 +173,59 @@ def test_preact_mode_vs_oracle(B):
     _check_grads(g, g_o, 2e-5, "preact")
 
 
+@pytest.mark.parametrize("T,B,gate", [(1, 16, 0), (6, 37, 0), (7, 64, 0), (9, 130, 0), (4, 21, 1), (5, 48, 2)])
+def test_lowrank_preact_contract_vs_oracle(T, B, gate):
+    """config-(4) shape (H=256, wRank=uRank=16) under FLAG_SAVE_PREACT: the forward saves the
+    pre-activation and the rank-space vector [U1.h | W1.x]; the backward is the split-precision
+    low-rank scan + split-K weight-gradient GEMMs.  All twelve outputs against the fp64 oracle."""
+    F, H, r = 32, 256, 16
+    GN = ["sigmoid", "relu", "tanh"]
+    rng = np.random.default_rng(300 + T + B)
+    p = O.make_params(F, H, r, r, dtype=np.float32, seed=17, randomize_scalars=True)
+    if gate == 1:      # relu gate: keep z around 0..1 (see test_seeded_vs_oracle_fp32)
+        for k in ("w1", "w2", "u1", "u2"):
+            p[k] = (0.55 * p[k]).astype(np.float32)     # the product of two factors scales by 0.3
+        p["bias_gate"] = (0.3 * p["bias_gate"] - 0.1).astype(np.float32)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    P = _param_tensors(p)
+    xt, ht, Gt = _t(x), _t(h0), _t(G)
+    SAVE_PREACT = 4
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, gate, direction=1, flags=SAVE_PREACT) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, gate, direction=1) != 2
+    hs, pre, m = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"],
+                                              P["nu"], ht, gate, P["w1"], P["w2"], P["u1"], P["u2"],
+                                              flags=SAVE_PREACT)
+    assert m.shape == (T, B, 2 * r)
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, m, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], gate, flags=SAVE_PREACT,
+                                         bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64, h64 = x.astype(np.float64), h0.astype(np.float64)
+    hs_o, zs_o, cs_o = O.unroll_forward(x64, p64, h64, gate=GN[gate])
+    hprev = np.concatenate([h64[None], hs_o[:-1]], 0)
+    m_o = np.concatenate([hprev @ p64["u1"].T, x64 @ p64["w1"].T], -1)
+    pre_o = m_o[..., r:] @ p64["w2"].T + m_o[..., :r] @ p64["u2"].T
+    rel = lambda a, ref: (np.abs(a - ref) / np.maximum(1.0, np.abs(ref))).max()
+    assert rel(hs.cpu().numpy(), hs_o) <= 1e-5
+    assert rel(m.cpu().numpy(), m_o) <= 1e-5
+    assert rel(pre.cpu().numpy(), pre_o) <= 1e-5
+    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64, gate=GN[gate])
+    tol = 2e-5
+    if gate == 1:      # same mask as the HIP path: the oracle in fp32 on the kernel's own states
+        hsn = hs.cpu().numpy()
+        zk = np.maximum(pre.cpu().numpy() + p["bias_gate"], 0).astype(np.float32)
+        ck = np.tanh(pre.cpu().numpy() + p["bias_update"]).astype(np.float32)
+        g_o = O.unroll_backward(G, x, hsn, zk, ck, p, h0, gate=GN[gate])
+        tol = 5e-5
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u",
+             "d_w1", "d_w2", "d_u1", "d_u2"]
+    assert outs[6].numel() == 0 and outs[7].numel() == 0
+    g = {n: o.cpu().numpy() for n, o in zip(names, outs) if o.numel()}
+    _check_grads(g, g_o, tol, "lowrank-preact")
+
+
 def test_single_step_operators():
     """forward / backward (fastgrnn_cuda.cpp:73-145) == T=1 oracle."""
     B, F, H = 37, 32, 128
@@ -205,7 +258,7 @@ def _copy_params(m, p):
 
 
 @pytest.mark.parametrize("batch_first", [False, True])
-@pytest.mark.parametrize("lowrank", [False, True])
+@pytest.mark.parametrize("lowrank", [False, True, "config4"])
 def test_module_autograd_matches_cpu_port(batch_first, lowrank):
     """FastGRNNCUDA (rnn.py:738-826) forward+autograd vs the torch CPU port of
     FastGRNNCell + BaseRNN loop (the reference's CPU path)."""
@@ -213,6 +266,8 @@ def test_module_autograd_matches_cpu_port(batch_first, lowrank):
     T, B, F, H = 30, 21, 32, 128
     torch.manual_seed(0)
     rw = ru = 8 if lowrank else None
+    if lowrank == "config4":             # BASELINE configs[3] shape: the low-rank split-precision kernels
+        H, rw, ru = 256, 16, 16
     cell = FastGRNNCellPort(F, H, wRank=rw, uRank=ru)
     with torch.no_grad():
         cell.bias_gate.add_(0.3 * torch.randn_like(cell.bias_gate)); cell.zeta.fill_(0.4); cell.nu.fill_(-3.0)
