@@ -73,6 +73,9 @@ typedef enum fastgrnn_nonlinearity {
  * h_prime_t from it and therefore needs params->bias_gate / bias_update.  Saves one [T,B,H] write
  * and one read per step against the reference operator's (z_s, h_prime_s) pair. */
 #define FASTGRNN_FLAG_SAVE_PREACT 4u
+/* A/B only: run the dense split-precision forward in its older 4-wave shape (one wave per SIMD, two
+ * row tiles per wave) instead of the default 8-wave one.  Same results to fp32 rounding. */
+#define FASTGRNN_FLAG_FWD_4WAVE 8u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {

@@ -19,6 +19,7 @@ F32, F64 = 0, 1
 FLAG_FORCE_GENERIC = 1
 FLAG_FORCE_F32_MFMA = 2
 FLAG_SAVE_PREACT = 4
+FLAG_FWD_4WAVE = 8            # A/B: older 4-wave forward shape
 
 # include/fastgrnn_hip.h: fastgrnn_nonlinearity.  0..2 are the reference's table
 # (rnn.py:478,751); 3..5 the CPU cell's quantised family (rnn.py:53-60).

@@ -283,6 +283,136 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, 8 waves  (H = 128, F = 32)
+// ------------------------------------------------------------------------------------------
+// Same arithmetic as fwd_scan_split, other shape: workgroup = 8 waves = 16 utterances, wave w owns
+// ONE 16-unit row tile (units 16w..16w+15), two waves per SIMD.  A wave's critical path per step is
+// one 30-MFMA chain + a 4-element epilogue; while it waits (chain latency, LDS round trip, barrier)
+// the SIMD's other wave issues, so matrix pipe and VALU overlap across waves without hand-placed
+// schedules.  State AND feature planes go through LDS in natural [utterance][unit] order: every lane
+// splits one feature value of the next frame, so the x split is not replicated per wave.
+constexpr int W8_ROWH = 272;            // bytes per utterance row of a 128-wide bf16 plane (256 + 16: conflict-free b128 reads)
+constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide bf16 plane (64 + 16)
+
+template <int GATE, int AUX, bool RAGGED>
+__global__ __launch_bounds__(512) void fwd_scan_split_w8(
+    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    const float* __restrict__ w, const float* __restrict__ u,
+    const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs) {
+  constexpr int H = 128, F = 32, KS = H / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char hpl[2][3][16 * W8_ROWH];
+  __shared__ __attribute__((aligned(16))) unsigned char xpl[2][3][16 * W8_ROWX];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 16 + g * 4;                  // this lane's 4 hidden units
+  // feature element this lane converts each step: utterance xu, feature xf
+  const int xu = tid >> 5, xf = tid & 31;
+  const int xb = blockIdx.x * 16 + xu;
+  const int xbc = (!RAGGED || xb < B) ? xb : B - 1;
+
+  Frag3 Uf[KS], Wf;
+  {
+    const int nA = wv * 16 + i;                    // A row i = unit 16w + i, K in natural unit order
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const float* up = u + (size_t)nA * H + 32 * s2 + 8 * g;
+      Uf[s2] = split3(ld4(up), ld4(up + 4));
+    }
+    const float* wp = w + (size_t)nA * F + 8 * g;
+    Wf = split3(ld4(wp), ld4(wp + 4));
+  }
+  const f32x4 bzv = ld4(bz + n0), bhv = ld4(bh + n0);
+  f32x4 hown = ld4(h0 + (size_t)bc * H + n0);
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+
+  // planes of this lane's 4 state values -> 8 bytes per plane at [utterance i][unit n0]
+  auto publish_h = [&](int buf) __attribute__((always_inline)) {
+    unsigned b0[4], b1[4], b2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b0[j] = fbits(hown[j]);
+      const float r1 = hown[j] - bitsf(b0[j] & 0xFFFF0000u);
+      b1[j] = fbits(r1);
+      const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
+      b2[j] = fbits(r2);
+    }
+    const unsigned off = i * W8_ROWH + n0 * 2;
+    *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
+    *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
+    *reinterpret_cast<uint2*>(&hpl[buf][2][off]) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
+  };
+  auto publish_x = [&](int buf, float v) __attribute__((always_inline)) {
+    const unsigned a0 = fbits(v);
+    const float r1 = v - bitsf(a0 & 0xFFFF0000u);
+    const unsigned a1 = fbits(r1);
+    const float r2 = r1 - bitsf(a1 & 0xFFFF0000u);
+    const unsigned a2 = fbits(r2);
+    const unsigned off = xu * W8_ROWX + xf * 2;
+    *reinterpret_cast<unsigned short*>(&xpl[buf][0][off]) = (unsigned short)(a0 >> 16);
+    *reinterpret_cast<unsigned short*>(&xpl[buf][1][off]) = (unsigned short)(a1 >> 16);
+    *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = (unsigned short)(a2 >> 16);
+  };
+  auto load_x = [&](int t) __attribute__((always_inline)) {
+    return x[((size_t)t * B + xbc) * F + xf];
+  };
+  auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
+    if (valid) {
+      const size_t o = ((size_t)t * B + b) * H + n0;
+      st4(hs + o, hown);
+      if (AUX == 2) st4(zs + o, aux);
+    }
+  };
+
+  publish_h(0);
+  publish_x(0, load_x(0));
+  float xnext = load_x(Tn > 1 ? 1 : 0);            // frame t+1, published during step t
+  __syncthreads();
+
+  f32x4 aux_prev = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < Tn; ++t) {
+    const int cur = t & 1;
+    const float xpub = xnext;
+    xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
+    Frag3 xB, hB[KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(&xpl[cur][p][i * W8_ROWX + 16 * g]);
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        hB[s2].p[p] = *reinterpret_cast<const u32x4*>(&hpl[cur][p][i * W8_ROWH + 64 * s2 + 16 * g]);
+    if (t > 0) store_step(t - 1, aux_prev);          // h_{t-1} and its pre-activation, under the chain
+    publish_x(cur ^ 1, xpub);
+    f32x4 a = mfma6(Wf, xB, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) a = mfma6(Uf[s2], hB[s2], a);                        // .cu:368
+    f32x4 zq, cq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                                        // .cu:55-58
+      const float z = gate_act<GATE>(a[r] + bzv[r]);
+      const float c = ftanh(a[r] + bhv[r]);
+      hown[r] = (sz * (1.0f - z) + sn) * c + hown[r] * z;
+      zq[r] = z; cq[r] = c;
+    }
+    if (AUX == 1 && valid) {                          // reference operator outputs: stored at once
+      const size_t o = ((size_t)t * B + b) * H + n0;
+      st4(zs + o, zq); st4(cs + o, cq);
+    }
+    aux_prev = a;
+    publish_h(cur ^ 1);
+    lds_barrier();
+  }
+  store_step(Tn - 1, aux_prev);
+}
+
+// ------------------------------------------------------------------------------------------
 // forward, low-rank  (H = 256, F = 32, wRank = uRank = 16: BASELINE config 4)
 // ------------------------------------------------------------------------------------------
 // pre = W2 (W1 x) + U2 (U1 h), evaluated factorised like the CPU cell (rnn.py:280-287).  Workgroup =
@@ -1190,6 +1320,13 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  if (!(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {        // default: the 8-wave shape
+    block = dim3(512);
+    if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true>); else go(fwd_scan_split_w8<GATE, 1, false>); }
+    else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true>); else go(fwd_scan_split_w8<GATE, 2, false>); }
+    else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true>); else go(fwd_scan_split_w8<GATE, 0, false>); }
+    return;
+  }
   if (aux == 1)      { if (ragged) go(fwd_scan_split<GATE, 1, true>); else go(fwd_scan_split<GATE, 1, false>); }
   else if (aux == 2) { if (ragged) go(fwd_scan_split<GATE, 2, true>); else go(fwd_scan_split<GATE, 2, false>); }
   else               { if (ragged) go(fwd_scan_split<GATE, 0, true>); else go(fwd_scan_split<GATE, 0, false>); }

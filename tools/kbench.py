@@ -43,10 +43,14 @@ def main():
         return fastgrnn_cuda.forward_unroll(x, w, u, bz, bh, zeta, nu, h0, 0, w1, w2, u1, u2,
                                             want_gates=gates, flags=a.flags)
 
-    hs, zs, cs = fwd()
+    outs = fwd()
+    preact = bool(a.flags & 4)
+    hs, zs = outs[0], outs[1]
+    cs = outs[2] if len(outs) > 2 else outs[1]
 
     def bwd():
-        return fastgrnn_cuda.backward_unroll(G, x, hs, zeta, nu, w, u, zs, cs, h0, w1, w2, u1, u2, 0, flags=a.flags)
+        return fastgrnn_cuda.backward_unroll(G, x, hs, zeta, nu, w, u, zs, cs, h0, w1, w2, u1, u2, 0, flags=a.flags,
+                                             bias_gate=bz if preact else None, bias_update=bh if preact else None)
 
     fns = {"fwd": lambda: fwd(True), "fwd_nogates": lambda: fwd(False), "bwd": bwd}
     for name in a.what.split(","):
