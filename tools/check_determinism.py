@@ -1,0 +1,47 @@
+"""Bitwise run-to-run repeatability of the shipped kernels (forward + backward, dense and low-rank).
+A rare difference means an on-chip race (e.g. a load landing in a register an in-flight MFMA still
+reads).  Usage: python tools/check_determinism.py [reps] [extra flag bits]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kws_amd import fastgrnn_cuda
+dev = torch.device("cuda:0")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+e = torch.empty(0)
+T, F = 99, 32
+bad_total = 0
+for (H, r, B) in ((128, 0, 4096), (128, 0, 50), (256, 16, 4096)):
+    torch.manual_seed(1)
+    if r:
+        w = u = e
+        w1 = 0.1 * torch.randn(r, F, device=dev); w2 = 0.1 * torch.randn(H, r, device=dev)
+        u1 = 0.1 * torch.randn(r, H, device=dev); u2 = 0.1 * torch.randn(H, r, device=dev)
+    else:
+        w = 0.1 * torch.randn(H, F, device=dev); u = 0.1 * torch.randn(H, H, device=dev)
+        w1 = w2 = u1 = u2 = e
+    bz = torch.randn(1, H, device=dev); bh = torch.randn(1, H, device=dev)
+    zeta = torch.ones(1, 1, device=dev); nu = -4 * torch.ones(1, 1, device=dev)
+    x = torch.randn(T, B, F, device=dev); h0 = 0.3 * torch.randn(B, H, device=dev); G = torch.randn(T, B, H, device=dev)
+    for preact in (4, 0):
+        fl = preact | extra
+        first = None
+        nbad = 0
+        for rep in range(reps):
+            outs = fastgrnn_cuda.forward_unroll(x, w, u, bz, bh, zeta, nu, h0, 0, w1, w2, u1, u2, flags=fl)
+            aux2 = outs[2] if len(outs) > 2 else outs[1]
+            g = fastgrnn_cuda.backward_unroll(G, x, outs[0], zeta, nu, w, u, outs[1], aux2, h0, w1, w2, u1, u2, 0, flags=fl,
+                                              bias_gate=bz if preact else None, bias_update=bh if preact else None)
+            torch.cuda.synchronize()
+            allo = [o for o in list(outs) + list(g) if o.numel()]
+            if first is None:
+                first = [o.clone() for o in allo]
+            else:
+                d = [int((a != b).sum()) for a, b in zip(allo, first)]
+                if any(d):
+                    nbad += 1
+                    if nbad <= 3:
+                        print("   H=%d r=%d B=%d flags=%d rep %d: differing element counts %s" % (H, r, B, fl, rep, d), flush=True)
+        print("H=%d r=%d B=%d flags=%d: %d of %d repetitions differ from the first" % (H, r, B, fl, nbad, reps - 1), flush=True)
+        bad_total += nbad
+sys.exit(1 if bad_total else 0)
