@@ -1240,43 +1240,184 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
   }
 }
 
-// bias / zeta / nu gradients of the low-rank backward: fixed-order sum over workgroups
-__global__ void reduce_lowrank_small(int nwg, const float* __restrict__ part, const float* __restrict__ zeta,
-                                     const float* __restrict__ nu, float* __restrict__ d_bz, float* __restrict__ d_bh,
-                                     float* __restrict__ d_zeta, float* __restrict__ d_nu) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // 0 .. 2*256+1
-  if (idx >= 2 * 256 + 2) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int wg = 0;
-  for (; wg + 3 < nwg; wg += 4) {
-    a0 += part[(size_t)wg * SLAB_LR + idx]; a1 += part[(size_t)(wg + 1) * SLAB_LR + idx];
-    a2 += part[(size_t)(wg + 2) * SLAB_LR + idx]; a3 += part[(size_t)(wg + 3) * SLAB_LR + idx];
+// ------------------------------------------------------------------------------------------
+// C[M,N] = A[:, :M]^T . B[:, :N] over R rows (R = T*B, huge; M, N small): split-precision, matrix pipe
+// ------------------------------------------------------------------------------------------
+// The weight gradients of the low-rank backward (.cu:546-555, factorised).  Workgroup = 4 waves = one
+// chunk of TN_CHUNK rows, staged 32 rows at a time: global fp32 -> three exact bf16 planes in LDS in
+// natural [row][column] order -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs into
+// register accumulators.  Each workgroup leaves its partial C in the workspace; tn_reduce sums them
+// in a fixed order.  MT x NT = 16x16 tiles of C; wave w owns tiles w, w+4, ...
+constexpr int TN_CHUNK = 800, TN_STAGE = 32;
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __restrict__ A, int lda,
+                                                     const float* __restrict__ B0, const float* __restrict__ B1,
+                                                     size_t shiftB, int ldb, float* __restrict__ part) {
+  constexpr int M = MT * 16, N = NT * 16, ROWA = M * 2 + 32, ROWB = N * 2 + 32;
+  constexpr int NTILE = MT * NT, TPW = (NTILE + 3) / 4;
+  constexpr int VA = (TN_STAGE * M / 4 + 255) / 256, VB = (TN_STAGE * N / 4 + 255) / 256;   // float4 per thread per stage
+  __shared__ __attribute__((aligned(16))) unsigned char la[3][TN_STAGE * ROWA];
+  __shared__ __attribute__((aligned(16))) unsigned char lb[3][TN_STAGE * ROWB];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+  const size_t r_begin = (size_t)blockIdx.x * TN_CHUNK;
+  const size_t r_end = (r_begin + TN_CHUNK < R) ? r_begin + TN_CHUNK : R;
+
+  f32x4 va[VA], vb[VB];
+  auto load_stage = [&](size_t r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < VA; ++j) {
+      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
+      const size_t r = r0 + row;
+      va[j] = (idx < TN_STAGE * M / 4 && r < r_end) ? ld4(A + r * lda + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
+      const size_t r = r0 + row;
+      const float* src = r < shiftB ? B0 + r * ldb : B1 + (r - shiftB) * ldb;   // H_prev: rows of t = 0 are h0
+      vb[j] = (idx < TN_STAGE * N / 4 && r < r_end) ? ld4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto split4 = [&](const f32x4 v, unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned off)
+      __attribute__((always_inline)) {
+    unsigned b0[4], b1[4], b2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b0[j] = fbits(v[j]);
+      const float r1 = v[j] - bitsf(b0[j] & 0xFFFF0000u);
+      b1[j] = fbits(r1);
+      const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
+      b2[j] = fbits(r2);
+    }
+    *reinterpret_cast<uint2*>(p0 + off) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
+    *reinterpret_cast<uint2*>(p1 + off) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
+    *reinterpret_cast<uint2*>(p2 + off) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < VA; ++j) {
+      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
+      if (idx < TN_STAGE * M / 4) split4(va[j], la[0], la[1], la[2], (unsigned)(row * ROWA + c4 * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
+      if (idx < TN_STAGE * N / 4) split4(vb[j], lb[0], lb[1], lb[2], (unsigned)(row * ROWB + c4 * 8));
+    }
+  };
+
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned la0 = (unsigned)(size_t)&la[0][0], lb0 = (unsigned)(size_t)&lb[0][0];
+  // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
+  const unsigned trA = la0 + (8 * g + q) * ROWA + 4 * pp * 2;
+  const unsigned trB = lb0 + (8 * g + q) * ROWB + 4 * pp * 2;
+
+  load_stage(r_begin);
+  for (size_t r0 = r_begin; r0 < r_end; r0 += TN_STAGE) {
+    __syncthreads();                                 // the previous stage's fragment reads are done
+    publish();
+    __syncthreads();
+    if (r0 + TN_STAGE < r_end) load_stage(r0 + TN_STAGE);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int tile = wv + 4 * k;
+      if (tile < NTILE) {                            // wave-uniform
+        const int mt = tile / NT, nt = tile % NT;
+        Frag3 fa, fb;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa.p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA) + mt * 32, ROWA);
+          fb.p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + nt * 32, ROWB);
+        }
+        acc[k] = mfma6(fa, fb, acc[k]);
+      }
+    }
   }
-  for (; wg < nwg; ++wg) a0 += part[(size_t)wg * SLAB_LR + idx];
-  const float t = (a0 + a1) + (a2 + a3);
-  if (idx < 256) d_bz[idx] = t;
-  else if (idx < 512) d_bh[idx - 256] = t;
-  else if (idx == 512) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }
-  else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }
+  // D row 4g + r of tile (mt, nt) is m = 16mt + 4g + r, column n = 16nt + (l & 15)
+  float* pc = part + (size_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int tile = wv + 4 * k;
+    if (tile < NTILE) {
+      const int mt = tile / NT, nt = tile % NT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pc[(size_t)(mt * 16 + 4 * g + r) * N + nt * 16 + (l & 15)] = acc[k][r];
+    }
+  }
 }
 
-// C[H,32] -> d_u2[H,16] | d_w2[H,16]
-__global__ void split_cols_16_16(int H, const float* __restrict__ C, float* __restrict__ a, float* __restrict__ b) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= H * 32) return;
-  const int n = idx >> 5, j = idx & 31;
-  if (j < 16) a[n * 16 + j] = C[idx]; else b[n * 16 + (j - 16)] = C[idx];
+// C[idx] = sum over workgroups, fixed order; optional column split of a [M, 32] result into two [M, 16]
+__global__ __launch_bounds__(1024) void tn_reduce(int nwg, int MN, const float* __restrict__ part,
+                                                  float* __restrict__ C0, float* __restrict__ C1, int split16) {
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
+  float a = 0.f;
+  if (idx < MN) {
+    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * MN + idx] : 0.f; }
+      a += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  sm[pid][o] = a;
+  __syncthreads();
+  if (pid == 0 && idx < MN) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    if (split16) { const int n = idx >> 5, j = idx & 31; if (j < 16) C0[n * 16 + j] = t; else C1[n * 16 + (j - 16)] = t; }
+    else C0[idx] = t;
+  }
 }
 
-struct LowrankBwdWs { size_t dpre, dm, part, tmp, splitk, total; };
+static inline int tn_nwg(size_t R) { return (int)((R + TN_CHUNK - 1) / TN_CHUNK); }
+
+// bias / zeta / nu gradients of the low-rank backward: fixed-order sum over workgroups
+__global__ __launch_bounds__(1024) void reduce_lowrank_small(int nwg, const float* __restrict__ part,
+                                                             const float* __restrict__ zeta, const float* __restrict__ nu,
+                                                             float* __restrict__ d_bz, float* __restrict__ d_bh,
+                                                             float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;               // 0 .. 2*256+1
+  float a = 0.f;
+  if (idx < 2 * 256 + 2) {
+    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * SLAB_LR + idx] : 0.f; }
+      a += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  sm[pid][o] = a;
+  __syncthreads();
+  if (pid == 0 && idx < 2 * 256 + 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    if (idx < 256) d_bz[idx] = t;
+    else if (idx < 512) d_bh[idx - 256] = t;
+    else if (idx == 512) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
+    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                      // .cu:117,545
+  }
+}
+
+struct LowrankBwdWs { size_t dpre, dm, part, splitk, total; };
 LowrankBwdWs lowrank_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   LowrankBwdWs L; size_t o = 0;
   L.dpre = o; o += align256(TB * 256 * 4);
   L.dm = o; o += align256(TB * 32 * 4);
   L.part = o; o += align256(nwg * SLAB_LR * 4);
-  L.tmp = o; o += align256(256 * 32 * 4);
-  L.splitk = o; o += tn_gemm_f32_ws(TB, 256, 32);      // the largest of the three products (16 x 256 is the same size)
+  L.splitk = o; o += align256((size_t)tn_nwg(TB) * 256 * 32 * 4);   // partial C of the largest product, per workgroup
   L.total = o;
   return L;
 }
@@ -1288,7 +1429,7 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   const LowrankBwdWs L = lowrank_bwd_layout(d);
   char* base = reinterpret_cast<char*>(ws);
   float* dpre = (float*)(base + L.dpre); float* dm = (float*)(base + L.dm); float* part = (float*)(base + L.part);
-  float* tmp = (float*)(base + L.tmp); float* splitk = (float*)(base + L.splitk);
+  float* splitk = (float*)(base + L.splitk);
   const int nwg = (d.B + 15) / 16;
   const size_t TB = (size_t)d.T * d.B;
   auto go = [&](auto kern) __attribute__((always_inline)) {
@@ -1298,15 +1439,24 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                        (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, dpre, dm, part);
   };
   if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true>); else go(bwd_scan_lowrank_split<GATE, false>);
-  hipLaunchKernelGGL(reduce_lowrank_small, dim3(3), dim3(256), 0, s, nwg, part, (const float*)p.zeta,
+  hipLaunchKernelGGL(reduce_lowrank_small, dim3((2 * 256 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
                      (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
                      (float*)g.d_nu);
   // d_u2 | d_w2 = d_pre^T . [m_h | m_x]     (.cu:546-555, factorised)
-  tn_gemm_f32(TB, 256, 32, dpre, 256, (const float*)m_s, (const float*)m_s, 0, 32, splitk, tmp, s);
-  hipLaunchKernelGGL(split_cols_16_16, dim3(32), dim3(256), 0, s, 256, tmp, (float*)g.d_u2, (float*)g.d_w2);
+  const int ng = tn_nwg(TB);
+  hipLaunchKernelGGL((tn_gemm_split<16, 2>), dim3(ng), dim3(256), 0, s, TB, dpre, 256, (const float*)m_s,
+                     (const float*)m_s, (size_t)0, 32, splitk);
+  hipLaunchKernelGGL(tn_reduce, dim3(256 * 32 / 64), dim3(1024), 0, s, ng, 256 * 32, splitk, (float*)g.d_u2,
+                     (float*)g.d_w2, 1);
   // d_u1 = d_m_h^T . H_prev  (rows of t = 0 are h0, the rest hs[t-1]);  d_w1 = d_m_x^T . X
-  tn_gemm_f32(TB, 16, 256, dm, 32, (const float*)h0, (const float*)hs, (size_t)d.B, 256, splitk, (float*)g.d_u1, s);
-  tn_gemm_f32(TB, 16, 32, dm + 16, 32, (const float*)x, (const float*)x, 0, 32, splitk, (float*)g.d_w1, s);
+  hipLaunchKernelGGL((tn_gemm_split<1, 16>), dim3(ng), dim3(256), 0, s, TB, dm, 32, (const float*)h0,
+                     (const float*)hs, (size_t)d.B, 256, splitk);
+  hipLaunchKernelGGL(tn_reduce, dim3(16 * 256 / 64), dim3(1024), 0, s, ng, 16 * 256, splitk, (float*)g.d_u1,
+                     (float*)nullptr, 0);
+  hipLaunchKernelGGL((tn_gemm_split<1, 2>), dim3(ng), dim3(256), 0, s, TB, dm + 16, 32, (const float*)x,
+                     (const float*)x, (size_t)0, 32, splitk);
+  hipLaunchKernelGGL(tn_reduce, dim3(16 * 32 / 64), dim3(1024), 0, s, ng, 16 * 32, splitk, (float*)g.d_w1,
+                     (float*)nullptr, 0);
 }
 
 template <int GATE>
