@@ -76,6 +76,11 @@ typedef enum fastgrnn_nonlinearity {
 /* A/B only: run the dense split-precision forward in its older 4-wave shape (one wave per SIMD, two
  * row tiles per wave) instead of the default 8-wave one.  Same results to fp32 rounding. */
 #define FASTGRNN_FLAG_FWD_4WAVE 8u
+/* Batch-major sequences (the trainer's batch_first layout, rnn.py:812-813,823-825): x, hs, z_s, c_s,
+ * grad_hs and d_x are [B,T,.] instead of [T,B,.]; h0/d_h0 stay [B,H].  Kernel path 2, dense operands
+ * only -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the caller transposes as the reference
+ * does.  Removes the transpose(0,1).contiguous() copies around the operator. */
+#define FASTGRNN_FLAG_BATCH_MAJOR 16u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {

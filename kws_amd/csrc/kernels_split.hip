@@ -124,7 +124,7 @@ __device__ __forceinline__ f32x4 mfma6(const Frag3& a, const Frag3& b, f32x4 acc
 // pre-activation W.x+U.h into zs (FASTGRNN_FLAG_SAVE_PREACT, consumed by bwd_scan_split<PREACT>).
 template <int GATE, int AUX, bool RAGGED>
 __global__ __launch_bounds__(256) void fwd_scan_split(
-    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void fwd_scan_split(
   struct Feat { f32x4 lo, hi; };          // x[t][b][8g .. 8g+7]
   struct Gates { f32x4 z[MT], c[MT]; };
   auto load_x = [&](int t, Feat& q) __attribute__((always_inline)) {
-    const float* xp = x + ((size_t)t * B + bc) * F + 8 * g;
+    const float* xp = x + ((size_t)t * rsT + (size_t)bc * rsB) * F + 8 * g;
     q.lo = ld4(xp); q.hi = ld4(xp + 4);
   };
   auto store_step = [&](int t, const Gates& gt) __attribute__((always_inline)) {   // hown still holds h_t
     if (valid) {
-      const size_t o = ((size_t)t * B + b) * H + n0;
+      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
       if (AUX == 1) {
@@ -296,7 +296,7 @@ constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide 
 
 template <int GATE, int AUX, bool RAGGED>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
-    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
@@ -360,11 +360,11 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = (unsigned short)(a2 >> 16);
   };
   auto load_x = [&](int t) __attribute__((always_inline)) {
-    return x[((size_t)t * B + xbc) * F + xf];
+    return x[((size_t)t * rsT + (size_t)xbc * rsB) * F + xf];
   };
   auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
     if (valid) {
-      const size_t o = ((size_t)t * B + b) * H + n0;
+      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
       st4(hs + o, hown);
       if (AUX == 2) st4(zs + o, aux);
     }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
       zq[r] = z; cq[r] = c;
     }
     if (AUX == 1 && valid) {                          // reference operator outputs: stored at once
-      const size_t o = ((size_t)t * B + b) * H + n0;
+      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
       st4(zs + o, zq); st4(cs + o, cq);
     }
     aux_prev = a;
@@ -582,6 +582,10 @@ __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::mak
 // floats per workgroup slab of backward partial sums, padded to 64: dU | dW | d_bz | d_bh | (zeta, nu)
 constexpr int SLAB = (128 * 128 + 128 * 32 + 2 * 128 + 2 + 63) & ~63;
 
+// row (t, b) of a [T,B,*] / [B,T,*] tensor = t * row_stride_t + b * row_stride_b
+static inline int row_stride_t(const fastgrnn_desc& d) { return (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) ? 1 : d.B; }
+static inline int row_stride_b(const fastgrnn_desc& d) { return (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) ? d.T : 1; }
+
 constexpr int ROW_H = 288;             // bytes per utterance row of a 128-wide bf16 plane (256 + 32 pad)
 constexpr int ROW_X = 96;              // bytes per utterance row of a 32-wide bf16 plane (64 + 32 pad)
 constexpr int PLANE_H = 16 * ROW_H;    // 4608
@@ -625,7 +629,7 @@ __device__ __forceinline__ u32x4 tr_frag(unsigned lds_byte_addr, int rowb) {
 // recomputed here; otherwise aux0 = z_s, aux1 = h_prime_s (the reference operator's tensors).
 template <int GATE, bool PREACT, bool RAGGED>
 __global__ __launch_bounds__(256) void bwd_scan_split(
-    int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ x,
+    int Tn, int B, int rsT, int rsB, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
     const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
@@ -710,8 +714,8 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   struct EwOps { f32x4 g[MT], a0[MT], a1[MT], h[MT]; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev
   struct XRaw { f32x4 lo, hi; };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t o = ((size_t)t * B + bc) * H + n0;
-    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)B * H;   // .cu:478-481
+    const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
+    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       e.g[mt] = ld4(ghs + o + 4 * mt);
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   };
   auto load_xraw = [&](int t, XRaw& r) __attribute__((always_inline)) {
     const int bb = blockIdx.x * 16 + xb;
-    const float* xp = x + ((size_t)t * B + ((!RAGGED || bb < B) ? bb : B - 1)) * F + xf0;
+    const float* xp = x + ((size_t)t * rsT + (size_t)((!RAGGED || bb < B) ? bb : B - 1) * rsB) * F + xf0;
     r.lo = ld4(xp); r.hi = ld4(xp + 4);
   };
 
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256) void bwd_scan_split(
   auto finish_dx = [&](int t) __attribute__((always_inline)) {
     if (wv < NFT) {                         // wave-uniform
       f32x4 sacc = (S.DX[t & 1][0][wv][l] + S.DX[t & 1][1][wv][l]) + (S.DX[t & 1][2][wv][l] + S.DX[t & 1][3][wv][l]);
-      if (valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, sacc);
+      if (valid) st4(d_x + ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g, sacc);
     }
   };
 
@@ -1033,7 +1037,8 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   const bool ragged = (d.B % 16) != 0, preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   float* part = reinterpret_cast<float*>(ws);
   auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)ghs, (const float*)x, (const float*)hs,
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d), (const float*)ghs,
+                       (const float*)x, (const float*)hs,
                        (const float*)a0, (const float*)a1, (const float*)h0, (const float*)p.w, (const float*)p.u,
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
@@ -1466,7 +1471,8 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   const bool ragged = (d.B % 16) != 0;
   const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
   auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d), (const float*)x,
+                       (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
@@ -1511,7 +1517,8 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
     return false;
   // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style
   // backward with z_s / h_prime_s stays on the generic scan)
-  if (lowrank_fwd_shape(d)) return direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  if (lowrank_fwd_shape(d))
+    return !(d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0);
   return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
          d.update_nl == FASTGRNN_NL_TANH && d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH &&
          d.H == 128 && d.F == 32;

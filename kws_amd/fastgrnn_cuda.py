@@ -140,10 +140,14 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     _check_input(input, "input")
     _check_input(bias_gate, "bias_gate"); _check_input(bias_update, "bias_update")
     _check_input(h0, "initial_h" if unrolled else "old_h")
+    batch_major = bool(flags & _lib.FLAG_BATCH_MAJOR)
     if unrolled:
         if input.dim() != 3:
             raise RuntimeError("input must be [timesteps, batch, features]")
-        T, B, F = input.shape
+        if batch_major:
+            B, T, F = input.shape
+        else:
+            T, B, F = input.shape
     else:
         if input.dim() != 2:
             raise RuntimeError("input must be [batch, features]")
@@ -158,7 +162,7 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     desc, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
                                    input.dtype, gate_nl, update_nl, flags)
     dev = input.device
-    oshape = (T, B, H) if unrolled else (B, H)
+    oshape = ((B, T, H) if batch_major else (T, B, H)) if unrolled else (B, H)
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
     with torch.cuda.device(dev):
         hs = torch.empty(oshape, dtype=input.dtype, device=dev)
@@ -198,10 +202,14 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
         _check_input(t, n)
     if unrolled:
-        T, B, F = input.shape
+        if flags & _lib.FLAG_BATCH_MAJOR:
+            B, T, F = input.shape
+        else:
+            T, B, F = input.shape
         H = grad_h.shape[-1]
-        _expect(grad_h, (T, B, H), "grad_h"); _expect(hs_or_old_h, (T, B, H), "hidden_states")
-        _expect(z, (T, B, H), "z"); _expect(h_prime, (T, B, H), "h_prime"); _expect(h0, (B, H), "initial_h")
+        lead = tuple(input.shape[:2])
+        _expect(grad_h, lead + (H,), "grad_h"); _expect(hs_or_old_h, lead + (H,), "hidden_states")
+        _expect(z, lead + (H,), "z"); _expect(h_prime, lead + (H,), "h_prime"); _expect(h0, (B, H), "initial_h")
     else:
         T = 1
         B, F = input.shape

@@ -67,10 +67,16 @@ class FastGRNNUnrollFunction(Function):
     backward recomputes the gates from it -- one [T,B,H] HBM write and read less per step."""
 
     @staticmethod
-    def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity):
+    def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity,
+                batch_major=False):
+        """``batch_major`` (not in the reference signature): ``input`` / the result are [B,T,.] and the
+        kernels index them in place (FLAG_BATCH_MAJOR) instead of working on transposed copies."""
         input = input.contiguous()
         old_h = old_h.contiguous()
-        T, B, F = input.shape
+        if batch_major:
+            B, T, F = input.shape
+        else:
+            T, B, F = input.shape
         H = old_h.shape[1]
         rw = w1.shape[0] if w1.numel() else 0
         ru = u1.shape[0] if u1.numel() else 0
@@ -78,6 +84,9 @@ class FastGRNNUnrollFunction(Function):
                   fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
                                             _lib.FLAG_SAVE_PREACT) == 2)
         flags = _lib.FLAG_SAVE_PREACT if preact else 0
+        if batch_major:
+            flags |= _lib.FLAG_BATCH_MAJOR
+        ctx.flags = flags
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
                                                gate_non_linearity, w1, w2, u1, u2, flags=flags)
         hidden_states = outputs[0]
@@ -100,14 +109,14 @@ class FastGRNNUnrollFunction(Function):
              w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     pre_s, aux2, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
-                                                    flags=_lib.FLAG_SAVE_PREACT, bias_gate=bias_gate,
+                                                    flags=ctx.flags, bias_gate=bias_gate,
                                                     bias_update=bias_update)
         else:
             (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     z_s, h_prime_s, old_h, w1, w2, u1, u2,
-                                                    ctx.gate_non_linearity)
-        return _as_autograd_grads(outputs, ctx.needs_input_grad)
+                                                    ctx.gate_non_linearity, flags=ctx.flags)
+        return _as_autograd_grads(outputs, ctx.needs_input_grad) + (None,)
 
 
 def _as_autograd_grads(outputs, needs):
@@ -255,19 +264,29 @@ class FastGRNNCUDA(nn.Module):
         """input: [timesteps, batch, features] (or [batch, timesteps, features] when
         ``batch_first``); hiddenState: [batch, state_size], zeros if not provided
         (rnn.py:807-826).  Returns every hidden state, same leading layout as the input."""
-        if self.batch_first is True:
-            input = input.transpose(0, 1).contiguous()
         if not input.is_cuda:
             input = input.to(self.device)
+        # batch_first: the reference transposes to [T,B,F] and back (rnn.py:812-813,823-825); where the
+        # kernels can index [B,T,.] in place (FLAG_BATCH_MAJOR) no copy is made at all
+        in_place = False
+        if self.batch_first is True:
+            Bn, Tn, Fn = input.shape
+            rw = self.W1.shape[0] if self.W1.numel() else 0
+            ru = self.U1.shape[0] if self.U1.numel() else 0
+            in_place = (input.dtype == torch.float32 and fastgrnn_cuda.kernel_path(
+                Tn, Bn, Fn, self._hidden_size, rw, ru, self._gate_non_linearity, 2, input.dtype, 1,
+                _lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2)
+            if not in_place:
+                input = input.transpose(0, 1).contiguous()
+        nbatch = input.shape[0] if in_place else input.shape[1]
         if hiddenState is None:
-            hiddenState = torch.zeros([input.shape[1], self._hidden_size], dtype=input.dtype,
-                                      device=input.device)
+            hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=input.dtype, device=input.device)
         if not hiddenState.is_cuda:
             hiddenState = hiddenState.to(self.device)
         result = FastGRNNUnrollFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu,
                                               hiddenState, self.W, self.U, self.W1, self.W2, self.U1, self.U2,
-                                              self._gate_non_linearity)
-        if self.batch_first is True:
+                                              self._gate_non_linearity, in_place)
+        if self.batch_first is True and not in_place:
             return result.transpose(0, 1)
         return result
 

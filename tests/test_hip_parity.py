@@ -485,3 +485,40 @@ def test_run_to_run_bitwise_repeatability():
             else:
                 for k, (a, b) in enumerate(zip(allo, first)):
                     assert torch.equal(a, b), (H, r, rep, k)
+
+
+@pytest.mark.parametrize("B,preact", [(37, True), (64, True), (48, False)])
+def test_batch_major_layout_equals_time_major(B, preact):
+    """FLAG_BATCH_MAJOR (N1: the trainer's batch_first layout indexed in place, rnn.py:812-813,823-825):
+    same arithmetic per utterance, so every output equals the time-major run bit for bit."""
+    T, F, H = 23, 32, 128
+    BATCH_MAJOR, SAVE_PREACT = 16, 4
+    p = O.make_params(F, H, seed=4, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    base = SAVE_PREACT if preact else 0
+    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"]) if preact else {}
+
+    def run(xi, Gi, flags):
+        outs = fastgrnn_cuda.forward_unroll(xi, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"],
+                                            h0, 0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+        gr = fastgrnn_cuda.backward_unroll(Gi, xi, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], h0,
+                                           P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags, **kw)
+        return list(outs), list(gr)
+
+    o_t, g_t = run(x, G, base)
+    o_b, g_b = run(x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous(), base | BATCH_MAJOR)
+    for a, b in zip(o_t, o_b):
+        assert b.shape == (B, T, H) and torch.equal(a, b.transpose(0, 1))
+    assert g_b[0].shape == (B, T, F) and torch.equal(g_t[0], g_b[0].transpose(0, 1))
+    for a, b in zip(g_t[1:8], g_b[1:8]):
+        assert torch.equal(a, b)
+    # not available off the dense split-precision path: the caller transposes instead
+    assert fastgrnn_cuda.kernel_path(T, B, F, 256, 16, 16, 0, direction=0, flags=base | BATCH_MAJOR) != 2
+    with pytest.raises(RuntimeError):
+        fastgrnn_cuda.forward_unroll(x.transpose(0, 1).contiguous(), P["w"], P["u"], P["bias_gate"], P["bias_update"],
+                                     P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"],
+                                     flags=BATCH_MAJOR | 1)
