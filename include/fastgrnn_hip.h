@@ -81,6 +81,8 @@ typedef enum fastgrnn_nonlinearity {
  * only -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the caller transposes as the reference
  * does.  Removes the transpose(0,1).contiguous() copies around the operator. */
 #define FASTGRNN_FLAG_BATCH_MAJOR 16u
+/* A/B only: run the dense split-precision backward as the older 4-wave kernel instead of the 8-wave one. */
+#define FASTGRNN_FLAG_BWD_4WAVE 32u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {

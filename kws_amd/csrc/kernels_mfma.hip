@@ -102,7 +102,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // 2 = no per-step barrier, 4 = cheap epilogue, 8 = no recurrent-chain MFMAs, 16 = cycle
 // stamps.  Ablations for timing; their results are wrong by construction.
 template <int H, int F, int GATE, bool GATES_OUT, bool RAGGED, int DIAG = 0>
-__global__ __launch_bounds__(256) void fwd_scan_mfma(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fwd_scan_mfma(
     int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
@@ -283,7 +283,7 @@ struct BwdLds {
 // d_pre; one raw s_barrier per step.  Global operands are requested one iteration before
 // their use into alternating register sets (no copies, no early waits).
 template <int H, int F, int GATE, bool RAGGED, int DIAG = 0>
-__global__ __launch_bounds__(256) void bwd_scan_mfma(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bwd_scan_mfma(
     int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ zs, const float* __restrict__ cs,
     const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
