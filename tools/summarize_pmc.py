@@ -10,7 +10,9 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("bwd_scan_split", "fwd_scan_split", "reduce_slabs_split", "bwd_scan_mfma", "fwd_scan_mfma",
+    for k in ("bwd_scan_split_w8", "fwd_scan_split_w8", "bwd_scan_lowrank_split", "fwd_scan_lowrank_split",
+              "tn_gemm_split", "tn_reduce", "reduce_lowrank_small",
+              "bwd_scan_split", "fwd_scan_split", "reduce_slabs_split", "bwd_scan_mfma", "fwd_scan_mfma",
               "reduce_slabs", "fwd_scan_generic", "bwd_scan_generic"):
         if k in name:
             return k
