@@ -382,8 +382,13 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   __syncthreads();
 
   f32x4 aux_prev = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   for (int t = 0; t < Tn; ++t) {
     const int cur = t & 1;
+    SPLIT_STAMP(0)
     const float xpub = xnext;
     xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
     Frag3 xB, hB[KS];
@@ -396,15 +401,16 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
         hB[s2].p[p] = *reinterpret_cast<const u32x4*>(&hpl[cur][p][i * W8_ROWH + 64 * s2 + 16 * g]);
     if (t > 0) store_step(t - 1, aux_prev);          // h_{t-1} and its pre-activation: issued during the LDS round trip
     publish_x(cur ^ 1, xpub);
-    // every fragment has landed, in registers of its own, before the first MFMA that reads one is issued
-    // (two waves per SIMD: see bwd_scan_split_w8::weight_grads for why the compiler must not stream them)
+    // every fragment read is ISSUED -- so each has registers of its own -- before the first MFMA that reads
+    // one (two waves per SIMD: see bwd_scan_split_w8::weight_grads for why the compiler must not stream
+    // them through fewer registers); the waits for them stay progressive
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
     f32x4 a = mfma6(Wf, xB, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) a = mfma6(Uf[s2], hB[s2], a);                        // .cu:368
     f32x4 zq, cq;
+    SPLIT_STAMP(2)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                                                        // .cu:55-58
       const float z = gate_act<GATE>(a[r] + bzv[r]);
@@ -418,8 +424,13 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     }
     aux_prev = a;
     publish_h(cur ^ 1);
+    SPLIT_STAMP(3)
     lds_barrier();
+    SPLIT_STAMP(4)
   }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
+#endif
   store_step(Tn - 1, aux_prev);
 }
 
@@ -1100,11 +1111,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   const unsigned trH_off = OFF_HP + (8 * (g & 1) + q) * ROW_H + (4 * pp) * 2;             // h_prev^T column 16c + i
   const unsigned trX_off = OFF_XP + (8 * (g & 1) + q) * ROW_X + (4 * pp) * 2;             // x^T column 16f + i
 
-  auto fragments_landed = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
+  // all fragment reads of a phase are issued (hence: each in registers of its own) before its first MFMA
+  auto fragments_landed = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   struct EwOps { f32x4 g, a0, a1, h; float xv; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev; one x value
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
@@ -1206,8 +1214,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
         bf.p[pl] = (ct < NFT) ? tr_frag(trX + pl * PLANE_X + ct * 32, ROW_X)
                               : tr_frag(trH + pl * PLANE_H + (ct - NFT) * 32, ROW_H);
     };
-    // Fragments land (all of a batch, each in registers of its own) BEFORE the first MFMA that reads one is
-    // issued, and a batch's registers are reloaded only after its last MFMA has RETIRED (a VALU read of the
+    // All fragment reads of a batch are issued (each into registers of its own) BEFORE the first MFMA that
+    // reads one, and a batch's registers are reloaded only after its last MFMA has RETIRED (a VALU read of the
     // youngest accumulators waits for it).  With two waves per SIMD an issued MFMA can sit behind the other
     // wave's MFMAs and fetches its operands when it starts: a ds_read into a fragment right after the MFMAs
     // that read it -- what the compiler emits when left alone -- gave rare run-to-run differences
@@ -1244,8 +1252,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       for (int p = 0; p < 3; ++p)
         dB[s2].p[p] = *reinterpret_cast<const u32x4*>(im + OFF_DP + p * PLANE_H + i * ROW_H + (32 * s2 + 8 * g) * 2);
     if (t + 1 < Tn) finish_dx(t + 1);               // partials published in the previous iteration
-    // All twelve fragments have LANDED, each in registers of its own, before the first MFMA that reads one is
-    // issued: the compiler would otherwise stream them through fewer registers (a ds_read into a fragment
+    // All twelve fragment reads are issued, each into registers of its own, before the first MFMA that reads
+    // one: the compiler would otherwise stream them through fewer registers (a ds_read into a fragment
     // right after the MFMAs that read it), which is not safe here -- see weight_grads.
     fragments_landed();
     EwPre f;
@@ -1700,8 +1708,8 @@ __global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __re
     publish();
     __syncthreads();
     if (r0 + TN_STAGE < r_end) load_stage(r0 + TN_STAGE);
-    // Several waves share a SIMD here (2 workgroups per CU): all of this stage's fragments land in registers
-    // of their own before the first MFMA is issued, and the MFMAs have retired before the next stage
+    // Several waves share a SIMD here (2 workgroups per CU): all of this stage's fragment reads are issued,
+    // into registers of their own, before the first MFMA, and the MFMAs have retired before the next stage
     // reloads them (see bwd_scan_split_w8::weight_grads).
     Frag3 fa[TPW], fb[TPW];
 #pragma unroll
@@ -1716,8 +1724,6 @@ __global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __re
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     float touch = 0.f;
 #pragma unroll
