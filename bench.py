@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io", choices=["f32", "bf16"], default="f32",
+                    help="sequence dtype: f32 (default; the reference's type) or bf16 frames/hidden states/grad_hs "
+                         "with fp32 state, parameters and parameter gradients (BASELINE config 'bf16 with fp32 master grads')")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -66,8 +69,9 @@ def main():
     torch.manual_seed(0)                         # identical parameters on every rank
     model = FastGRNNCUDA(F, H, device=dev)       # reference init: 0.1*randn, biases 1, zeta 1, nu -4
     g = torch.Generator().manual_seed(1000 + rank)
-    x = torch.randn(T, B, F, generator=g).to(dev)
-    G = torch.randn(T, B, H, generator=g).to(dev)
+    seq_dtype = torch.bfloat16 if args.io == "bf16" else torch.float32
+    x = torch.randn(T, B, F, generator=g).to(seq_dtype).to(dev)
+    G = torch.randn(T, B, H, generator=g).to(seq_dtype).to(dev)
     params = [p for p in model.parameters()]
     bucket = GradBucket(params, world) if world > 1 else None
 
@@ -122,7 +126,11 @@ def main():
             "metric": "utterances/sec fwd+bwd, T=99 feat=32 hidden=128, bs=4096 at 1/2/4/8 GPUs",
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (3xbf16 split MFMA, fp32 accumulate)" if fastgrnn_cuda.kernel_path(T, B, F, H, direction=1) == 2 else "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("bf16 sequences (x, hs, grad_hs, d_x); fp32 state, parameters, gradients (3xbf16 split MFMA, fp32 accumulate)"
+                      if args.io == "bf16" else
+                      "f32 (3xbf16 split MFMA, fp32 accumulate)" if split else "f32"),
+            "data": "synthetic",
             "config": {"workload": "FastGRNN dense fwd+bwd training step (FastGRNNCUDA module + autograd), T=99 F=32 "
                                    "H=128 B=%d per GPU, fp32 results, dense grad_hs; %s" % (
                                        B, "3xbf16 split-precision MFMA kernels, one saved [T,B,H] tensor" if split

@@ -56,7 +56,14 @@ typedef enum fastgrnn_status {
 
 typedef enum fastgrnn_dtype {
   FASTGRNN_F32 = 0,                /* mandatory type of the reference (AT_DISPATCH_FLOATING_TYPES, .cu:158) */
-  FASTGRNN_F64 = 1                 /* gradcheck type of the reference dispatch */
+  FASTGRNN_F64 = 1,                /* gradcheck type of the reference dispatch */
+  /* BASELINE config "bf16 with fp32 master grads" (new; the reference has no such type): the SEQUENCES
+   * x, hs, grad_hs and d_x are bf16 (2 bytes per element); parameters, h0 / d_h0, the saved
+   * pre-activation and every parameter gradient stay fp32, and so does all arithmetic (the state is
+   * carried in fp32 and only its stored copy is rounded, to nearest even).  Kernel path 2, dense
+   * H=128/F=32; forward without gates or with FASTGRNN_FLAG_SAVE_PREACT, backward with
+   * FASTGRNN_FLAG_SAVE_PREACT; anything else answers FASTGRNN_ERR_UNSUPPORTED. */
+  FASTGRNN_BF16_IO = 2
 } fastgrnn_dtype;
 
 typedef enum fastgrnn_nonlinearity {

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("FASTGRNN_HIP_LIB") or os.path.join(_HERE, "csrc", "li
 
 ABI_VERSION = 1
 
-F32, F64 = 0, 1
+F32, F64, BF16_IO = 0, 1, 2     # fastgrnn_dtype; BF16_IO: bf16 sequences, fp32 everything else
 FLAG_FORCE_GENERIC = 1
 FLAG_FORCE_F32_MFMA = 2
 FLAG_SAVE_PREACT = 4

@@ -16,7 +16,7 @@ int check_desc(const fastgrnn_desc* d) {
   // every tensor is indexed with size_t inside the kernels; keep T*B*max(H,F) below 2^40
   if ((double)d->T * d->B * (d->H > d->F ? d->H : d->F) > 1099511627776.0) return FASTGRNN_ERR_BAD_SHAPE;
   if (!nl_ok(d->gate_nl) || !nl_ok(d->update_nl)) return FASTGRNN_ERR_BAD_NONLINEARITY;
-  if (d->dtype != FASTGRNN_F32 && d->dtype != FASTGRNN_F64) return FASTGRNN_ERR_BAD_DTYPE;
+  if (d->dtype != FASTGRNN_F32 && d->dtype != FASTGRNN_F64 && d->dtype != FASTGRNN_BF16_IO) return FASTGRNN_ERR_BAD_DTYPE;
   return FASTGRNN_OK;
 }
 
@@ -91,7 +91,8 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   if (!x || !h0 || !hs) return FASTGRNN_ERR_NULL_POINTER;
-  if ((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR)) && pick_path(d, 0) != 2)
+  if (((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR)) || d->dtype == FASTGRNN_BF16_IO) &&
+      pick_path(d, 0) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_forward_workspace_bytes(d)))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -109,7 +110,8 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   const bool preact = (d->flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  if ((preact || (d->flags & FASTGRNN_FLAG_BATCH_MAJOR)) && pick_path(d, 1) != 2) return FASTGRNN_ERR_UNSUPPORTED;
+  if ((preact || (d->flags & FASTGRNN_FLAG_BATCH_MAJOR) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
+    return FASTGRNN_ERR_UNSUPPORTED;
   if (!grad_hs || !x || !hs || !z_s || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
   if (!g->d_x || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)
     return FASTGRNN_ERR_NULL_POINTER;

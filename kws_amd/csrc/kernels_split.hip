@@ -51,6 +51,22 @@ template <int GATE> __device__ __forceinline__ float gate_dact(float y) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// bf16 I/O variant (FASTGRNN_BF16_IO): sequences x / hs / grad_hs / d_x are bf16 in HBM, everything else fp32
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float f) {          // round to nearest even (finite inputs)
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ f32x4 ld4_bf16(const void* p) {               // 4 consecutive bf16 -> 4 floats
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u),
+               __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void st4_bf16(void* p, const f32x4 v) {
+  *reinterpret_cast<uint2*>(p) = uint2{f32_to_bf16_rne(v[0]) | (f32_to_bf16_rne(v[1]) << 16),
+                                       f32_to_bf16_rne(v[2]) | (f32_to_bf16_rne(v[3]) << 16)};
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
 constexpr int W8_ROWH = 272;            // bytes per utterance row of a 128-wide bf16 plane (256 + 16: conflict-free b128 reads)
 constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide bf16 plane (64 + 16)
 
-template <int GATE, int AUX, bool RAGGED>
+template <int GATE, int AUX, bool RAGGED, bool BF = false>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -366,13 +382,14 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = (unsigned short)(a2 >> 16);
   };
   auto load_x = [&](int t) __attribute__((always_inline)) {
-    return x[((size_t)t * rsT + (size_t)xbc * rsB) * F + xf];
+    const size_t e = ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
+    return BF ? bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[e]) : x[e];
   };
   auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
     if (valid) {
       const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
-      st4(hs + o, hown);
-      if (AUX == 2) st4(zs + o, aux);
+      if (BF) st4_bf16(reinterpret_cast<unsigned short*>(hs) + o, hown); else st4(hs + o, hown);
+      if (AUX == 2) st4(zs + o, aux);               // the saved pre-activation stays fp32
     }
   };
 
@@ -1033,7 +1050,7 @@ struct BwdW8Lds {
   float red[16];
 };
 
-template <int GATE, bool PREACT, bool RAGGED>
+template <int GATE, bool PREACT, bool RAGGED, bool BF = false>
 __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     int Tn, int B, int rsT, int rsB, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
@@ -1116,12 +1133,20 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   struct EwOps { f32x4 g, a0, a1, h; float xv; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev; one x value
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
-    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
-    e.g = ld4(ghs + o);
     e.a0 = ld4(aux0 + o);
     if (!PREACT) e.a1 = ld4(aux1 + o);
-    e.h = ld4(hprev);
-    e.xv = x[((size_t)t * rsT + (size_t)xbc * rsB) * F + xf];
+    const size_t ex = ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
+    if (BF) {                                        // bf16 sequences; h0 and the saved tensor are fp32
+      e.g = ld4_bf16(reinterpret_cast<const unsigned short*>(ghs) + o);
+      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);
+      else e.h = ld4_bf16(reinterpret_cast<const unsigned short*>(hs) + o - (size_t)rsT * H);
+      e.xv = bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[ex]);
+    } else {
+      const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
+      e.g = ld4(ghs + o);
+      e.h = ld4(hprev);
+      e.xv = x[ex];
+    }
   };
   struct EwPre { f32x4 kc, kz, z, c; };
   auto ew_pre = [&](const EwOps& e, EwPre& f) __attribute__((always_inline)) {
@@ -1193,7 +1218,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   auto finish_dx = [&](int t) __attribute__((always_inline)) {
     if (wv < NFT) {                         // wave-uniform: feature tile wv = sum over the four K-steps
       const f32x4 sacc = (S.DX[t & 1][wv][l] + S.DX[t & 1][wv + 2][l]) + (S.DX[t & 1][wv + 4][l] + S.DX[t & 1][wv + 6][l]);
-      if (valid) st4(d_x + ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g, sacc);
+      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g;
+      if (valid) { if (BF) st4_bf16(reinterpret_cast<unsigned short*>(d_x) + o, sacc); else st4(d_x + o, sacc); }
     }
   };
   // dW += d_pre_s^T x_s, dU += d_pre_s^T h_{s-1} (.cu:539-540) for the step pair (sU, sU-1): this wave's
@@ -1417,7 +1443,10 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   };
   // 8-wave kernel for the one-saved-tensor contract (9-11 % faster in the same run); with the reference
   // operator's (z_s, h_prime_s) pair its extra operand set costs more registers than it gains
-  if ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact) {
+  if (d.dtype == FASTGRNN_BF16_IO) {
+    block = dim3(512);
+    if (ragged) go(bwd_scan_split_w8<GATE, true, true, true>); else go(bwd_scan_split_w8<GATE, true, false, true>);
+  } else if ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact) {
     if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
     else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
   } else {
@@ -1866,6 +1895,12 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  if (d.dtype == FASTGRNN_BF16_IO) {                 // bf16 sequences: 8-wave kernel, hs only or hs + pre-activation
+    block = dim3(512);
+    if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, true>); else go(fwd_scan_split_w8<GATE, 2, false, true>); }
+    else          { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, true>); else go(fwd_scan_split_w8<GATE, 0, false, true>); }
+    return;
+  }
   if (!(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {        // default: the 8-wave shape
     block = dim3(512);
     if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true>); else go(fwd_scan_split_w8<GATE, 1, false>); }
@@ -1902,16 +1937,17 @@ bool lowrank_fwd_shape(const fastgrnn_desc& d) {
 }  // namespace
 
 bool split_supported(const fastgrnn_desc& d, int direction) {
-  if (d.dtype != FASTGRNN_F32 || d.update_nl != FASTGRNN_NL_TANH || d.gate_nl < FASTGRNN_NL_SIGMOID ||
-      d.gate_nl > FASTGRNN_NL_TANH)
+  if ((d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO) || d.update_nl != FASTGRNN_NL_TANH ||
+      d.gate_nl < FASTGRNN_NL_SIGMOID || d.gate_nl > FASTGRNN_NL_TANH)
     return false;
+  const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32;
+  // bf16 sequences: dense shape only; the backward only under the SAVE_PREACT contract (8-wave kernel)
+  if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0);
   // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style
   // backward with z_s / h_prime_s stays on the generic scan)
   if (lowrank_fwd_shape(d))
     return !(d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0);
-  return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 &&
-         d.update_nl == FASTGRNN_NL_TANH && d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH &&
-         d.H == 128 && d.F == 32;
+  return dense;
 }
 
 size_t split_backward_ws(const fastgrnn_desc& d) {
@@ -1942,6 +1978,7 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                   void* zs, void* cs, void*, hipStream_t s) {
   if (!(d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
+  if (d.dtype == FASTGRNN_BF16_IO && zs && !(d.flags & FASTGRNN_FLAG_SAVE_PREACT)) return FASTGRNN_ERR_UNSUPPORTED;
   if (lowrank_fwd_shape(d)) {
     if ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (!zs || !cs)) return FASTGRNN_ERR_NULL_POINTER;
     switch (d.gate_nl) {

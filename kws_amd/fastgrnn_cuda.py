@@ -30,7 +30,12 @@ import torch
 
 from . import _lib
 
-_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64, torch.bfloat16: _lib.BF16_IO}
+
+
+def _param_dtype(io_dtype):
+    """bf16 sequences (x, hs, grad_hs, d_x) go with fp32 parameters, h0 and gradients."""
+    return torch.float32 if io_dtype == torch.bfloat16 else io_dtype
 
 # Optional per-launch timing (bench.py): when set to a list, every C-ABI call appends
 # (tag, start_event, end_event) recorded on the stream the kernels are launched on.
@@ -82,7 +87,8 @@ def _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu
               update_nl, flags):
     """Validate parameters against (F,H) and build the C descriptor + params struct."""
     if dtype not in _DTYPES:
-        raise RuntimeError("fastgrnn: unsupported dtype %s (float32/float64 only)" % dtype)
+        raise RuntimeError("fastgrnn: unsupported dtype %s (float32/float64, or bfloat16 sequences)" % dtype)
+    io_dtype, dtype = dtype, _param_dtype(dtype)
     w_lr, u_lr = _present(w1), _present(u1)
     if w_lr:
         _check_input(w1, "w1"); _check_input(w2, "w2")
@@ -108,7 +114,7 @@ def _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu
     for t in tensors:
         if t.dtype != dtype:
             raise RuntimeError("fastgrnn: all operands must share dtype %s (got %s)" % (dtype, t.dtype))
-    desc = _lib.Desc(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), _DTYPES[dtype], int(flags))
+    desc = _lib.Desc(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), _DTYPES[io_dtype], int(flags))
     params = _lib.Params(_ptr(None if w_lr else w), _ptr(None if u_lr else u),
                          _ptr(w1 if w_lr else None), _ptr(w2 if w_lr else None),
                          _ptr(u1 if u_lr else None), _ptr(u2 if u_lr else None),
@@ -157,8 +163,10 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     _expect(h0, (B, H), "initial_h" if unrolled else "old_h")
     if bias_gate.numel() != H or bias_update.numel() != H:
         raise RuntimeError("bias_gate/bias_update must hold H=%d elements" % H)
-    if h0.dtype != input.dtype:
-        raise RuntimeError("input and hidden state dtypes differ")
+    pdt = _param_dtype(input.dtype)
+    if h0.dtype != pdt:
+        raise RuntimeError("input and hidden state dtypes differ" if pdt == input.dtype
+                           else "bfloat16 sequences take a float32 hidden state")
     desc, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
                                    input.dtype, gate_nl, update_nl, flags)
     dev = input.device
@@ -166,11 +174,11 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
     with torch.cuda.device(dev):
         hs = torch.empty(oshape, dtype=input.dtype, device=dev)
-        zs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates or preact) else None
-        cs = torch.empty(oshape, dtype=input.dtype, device=dev) if (want_gates and not preact) else None
+        zs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates or preact) else None
+        cs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates and not preact) else None
         if preact and desc.w_rank and desc.u_rank:
             # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step
-            cs = torch.empty((T, B, desc.w_rank + desc.u_rank), dtype=input.dtype, device=dev)
+            cs = torch.empty((T, B, desc.w_rank + desc.u_rank), dtype=pdt, device=dev)
         nbytes = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))
         ws, wsp = _workspace(nbytes, dev)
         fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
@@ -217,8 +225,9 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         _expect(grad_h, (B, H), "grad_h"); _expect(h0, (B, H), "old_h")
         _expect(z, (B, H), "z"); _expect(h_prime, (B, H), "h_prime")
     dt = input.dtype
-    for t in (grad_h, hs_or_old_h, z, h_prime, h0):
-        if t.dtype != dt:
+    pdt = _param_dtype(dt)
+    for t, want in ((grad_h, dt), (hs_or_old_h, dt if unrolled else pdt), (z, pdt), (h_prime, pdt), (h0, pdt)):
+        if t.dtype != want:
             raise RuntimeError("fastgrnn backward: operand dtypes differ")
     # biases are not needed by the backward when z, h_prime are given: pass zeta as a dummy
     desc, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2,
@@ -226,9 +235,9 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                                          zeta, nu, dt, gate_nl, update_nl, flags)
     dev = input.device
     with torch.cuda.device(dev):
-        mk = lambda *s: torch.empty(s, dtype=dt, device=dev)
+        mk = lambda *s: torch.empty(s, dtype=pdt, device=dev)
         none = lambda: torch.empty(0)
-        d_input = mk(*input.shape)
+        d_input = torch.empty(tuple(input.shape), dtype=dt, device=dev)
         d_bz, d_bh = mk(1, H), mk(1, H)
         d_zeta, d_nu = mk(1, 1), mk(1, 1)
         d_old_h = mk(B, H)

@@ -80,7 +80,7 @@ class FastGRNNUnrollFunction(Function):
         H = old_h.shape[1]
         rw = w1.shape[0] if w1.numel() else 0
         ru = u1.shape[0] if u1.numel() else 0
-        preact = (input.dtype == torch.float32 and input.is_cuda and
+        preact = (input.dtype in (torch.float32, torch.bfloat16) and input.is_cuda and
                   fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
                                             _lib.FLAG_SAVE_PREACT) == 2)
         flags = _lib.FLAG_SAVE_PREACT if preact else 0
@@ -273,14 +273,16 @@ class FastGRNNCUDA(nn.Module):
             Bn, Tn, Fn = input.shape
             rw = self.W1.shape[0] if self.W1.numel() else 0
             ru = self.U1.shape[0] if self.U1.numel() else 0
-            in_place = (input.dtype == torch.float32 and fastgrnn_cuda.kernel_path(
+            in_place = (input.dtype in (torch.float32, torch.bfloat16) and fastgrnn_cuda.kernel_path(
                 Tn, Bn, Fn, self._hidden_size, rw, ru, self._gate_non_linearity, 2, input.dtype, 1,
                 _lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2)
             if not in_place:
                 input = input.transpose(0, 1).contiguous()
         nbatch = input.shape[0] if in_place else input.shape[1]
         if hiddenState is None:
-            hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=input.dtype, device=input.device)
+            # bf16 sequences (BASELINE config "bf16 with fp32 master grads") keep an fp32 state and parameters
+            hdt = torch.float32 if input.dtype == torch.bfloat16 else input.dtype
+            hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=hdt, device=input.device)
         if not hiddenState.is_cuda:
             hiddenState = hiddenState.to(self.device)
         result = FastGRNNUnrollFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu,

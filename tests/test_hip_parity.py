@@ -522,3 +522,85 @@ def test_batch_major_layout_equals_time_major(B, preact):
         fastgrnn_cuda.forward_unroll(x.transpose(0, 1).contiguous(), P["w"], P["u"], P["bias_gate"], P["bias_update"],
                                      P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"],
                                      flags=BATCH_MAJOR | 1)
+
+
+@pytest.mark.parametrize("B,batch_major", [(64, False), (37, False), (48, True)])
+def test_bf16_sequences_fp32_master_grads(B, batch_major):
+    """BASELINE config "fwd+bwd training step, bf16 with fp32 master grads" (parity unpinned by the
+    reference, which has no such type): x, hs, grad_hs, d_x are bf16 in HBM; state, parameters, the
+    saved pre-activation and every parameter gradient are fp32.  Checked against the fp64 oracle run
+    on the SAME rounded tensors: hs and d_x to bf16 rounding (2^-8 relative), the fp32 outputs to the
+    fp32 tolerances of the other tests."""
+    T, F, H = 31, 32, 128
+    SAVE_PREACT, BATCH_MAJOR = 4, 16
+    rng = np.random.default_rng(77 + B)
+    p = O.make_params(F, H, dtype=np.float32, seed=23, randomize_scalars=True)
+    P = _param_tensors(p)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)
+    x_bf = bf(rng.standard_normal((T, B, F)).astype(np.float32))
+    G_bf = bf(rng.standard_normal((T, B, H)).astype(np.float32))
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    flags = SAVE_PREACT | (BATCH_MAJOR if batch_major else 0)
+    lay = (lambda t: t.transpose(0, 1).contiguous()) if batch_major else (lambda t: t)
+    unlay = (lambda t: t.transpose(0, 1)) if batch_major else (lambda t: t)
+    xt, Gt, ht = lay(x_bf).to(DEV), lay(G_bf).to(DEV), _t(h0)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=1, flags=flags) == 2
+    hs, pre = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                           0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+    assert hs.dtype == torch.bfloat16 and pre.dtype == torch.float32
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags,
+                                         bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    assert outs[0].dtype == torch.bfloat16 and outs[6].dtype == torch.float32
+    # ---- forward against the oracle on the rounded x: fp32 state inside, bf16 only when stored
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = x_bf.to(torch.float64).numpy(); G64 = G_bf.to(torch.float64).numpy(); h64 = h0.astype(np.float64)
+    hs_o, zs_o, cs_o = O.unroll_forward(x64, p64, h64)
+    hs_k = unlay(hs).to(torch.float64).cpu().numpy()
+    assert (np.abs(hs_k - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 2.0 ** -8 + 1e-5   # one bf16 rounding (RNE: 2^-9 relative)
+    hprev = np.concatenate([h64[None], hs_o[:-1]], 0)
+    assert np.abs(unlay(pre).cpu().numpy() - (x64 @ p64["w"].T + hprev @ p64["u"].T)).max() <= 1e-5
+    # ---- backward: the kernel sees the ROUNDED hs as h_prev (what autograd with bf16 activations does):
+    #      oracle on the same tensors, gates from the exact pre-activation
+    hs_r = hs_k.copy()
+    pre_k = unlay(pre).cpu().numpy().astype(np.float64)
+    z_k = 1.0 / (1.0 + np.exp(-(pre_k + p64["bias_gate"]))); c_k = np.tanh(pre_k + p64["bias_update"])
+    g_o = O.unroll_backward(G64, x64, hs_r, z_k, c_k, p64, h64)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+    g = {n: o for n, o in zip(names, outs[:8])}
+    dx = unlay(g.pop("d_x")).to(torch.float64).cpu().numpy()
+    ref = g_o.pop("d_x")
+    assert (np.abs(dx - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2.0 ** -8 + 2e-5
+    _check_grads({k: v.cpu().numpy() for k, v in g.items()}, g_o, 2e-5, "bf16-io")
+    # the reference's (z_s, h_prime_s) contract is not offered for bf16 sequences
+    with pytest.raises(RuntimeError):
+        fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                     0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags & ~SAVE_PREACT)
+
+
+def test_module_bf16_sequences_autograd():
+    """FastGRNNCUDA fed bf16 frames: bf16 hidden states out, bf16 d_input and fp32 parameter gradients
+    back; agrees with the same module run in fp32 on the rounded frames to bf16 rounding."""
+    T, B, F, H = 25, 40, 32, 128
+    torch.manual_seed(5)
+    m = FastGRNNCUDA(F, H, device=DEV)
+    x = torch.randn(T, B, F).to(torch.bfloat16)
+    G = torch.randn(T, B, H).to(torch.bfloat16)
+    xb = x.to(DEV).requires_grad_(True)
+    hb = m(xb)
+    assert hb.dtype == torch.bfloat16
+    hb.backward(G.to(DEV))
+    gb = {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+    dxb = xb.grad.clone()
+    assert dxb.dtype == torch.bfloat16 and all(v.dtype == torch.float32 for v in gb.values())
+    for p_ in m.parameters():
+        p_.grad = None
+    xf = x.float().to(DEV).requires_grad_(True)
+    hf = m(xf)
+    hf.backward(G.float().to(DEV))
+    assert ((hb.float() - hf).abs() / hf.abs().clamp(min=1.0)).max() <= 2.0 ** -8 + 1e-5
+    assert ((dxb.float() - xf.grad).abs() / xf.grad.abs().clamp(min=1.0)).max() <= 2.0 ** -7
+    for n, p_ in m.named_parameters():
+        scale = max(1.0, float(p_.grad.abs().max()))
+        # h_prev enters dU / d_zeta through its bf16-rounded copy: relative 2^-9 per term, random sign
+        assert (gb[n] - p_.grad).abs().max() / scale <= 1e-2, n
