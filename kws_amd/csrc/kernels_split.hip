@@ -1130,22 +1130,36 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
 
   // all fragment reads of a phase are issued (hence: each in registers of its own) before its first MFMA
   auto fragments_landed = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
-  struct EwOps { f32x4 g, a0, a1, h; float xv; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev; one x value
+  // grad_hs, aux0 (z or pre), aux1 (c), h_prev; one x value.  bf16 sequences stay RAW (packed) until they are
+  // used an iteration later: unpacking at load time would make every request synchronous.
+  struct EwOps { f32x4 g, a0, a1, h; float xv; uint2 graw, hraw; unsigned short xraw; };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
     e.a0 = ld4(aux0 + o);
     if (!PREACT) e.a1 = ld4(aux1 + o);
     const size_t ex = ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
-    if (BF) {                                        // bf16 sequences; h0 and the saved tensor are fp32
-      e.g = ld4_bf16(reinterpret_cast<const unsigned short*>(ghs) + o);
-      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);
-      else e.h = ld4_bf16(reinterpret_cast<const unsigned short*>(hs) + o - (size_t)rsT * H);
-      e.xv = bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[ex]);
+    if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
+      e.graw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + o);
+      e.hraw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(hs) + (t == 0 ? o : o - (size_t)rsT * H));
+      e.xraw = reinterpret_cast<const unsigned short*>(x)[ex];
     } else {
       const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
       e.g = ld4(ghs + o);
       e.h = ld4(hprev);
       e.xv = x[ex];
+    }
+  };
+  auto unpack4 = [](const uint2 v) __attribute__((always_inline)) {
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
+  };
+  // the operands of EW(t) as fp32 (a no-op for fp32 sequences)
+  auto unpack_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    if (BF) {
+      e.g = unpack4(e.graw);
+      e.h = unpack4(e.hraw);
+      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);   // once per launch
+      e.xv = bf16_to_f32(e.xraw);
     }
   };
   struct EwPre { f32x4 kc, kz, z, c; };
@@ -1265,7 +1279,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
 
   const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
   // One iteration.  eo = operands of EW(t-1) (requested an iteration ago); e_load receives those of EW(t-2).
-  auto iter = [&](auto last_tag, auto even_tag, int t, const EwOps& eo, EwOps& e_load) __attribute__((always_inline)) {
+  auto iter = [&](auto last_tag, auto even_tag, int t, EwOps& eo, EwOps& e_load) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value, EVEN = decltype(even_tag)::value;
     SPLIT_STAMP(0)
     constexpr bool MY_TURN = EVEN ? (ch == 0) : (ch == 1);
@@ -1296,7 +1310,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     // complementary order, EW first in the wave whose turn it is not, was 6 % slower in the same run.)
     chain();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LAST) ew_pre(eo, f);
+    if constexpr (!LAST) { unpack_ew(t - 1, eo); ew_pre(eo, f); }
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
     // reading dh (.cu:474) also means every chain MFMA has retired before a later load reuses a fragment register
@@ -1322,11 +1336,11 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     if ((Tn - 1) & 1) {
       load_ew(Tn - 1, E1);
       if (Tn >= 2) load_ew(Tn - 2, E0);
-      ew_pre(E1, f); ew_post(Tn - 1, E1, f, E1.g);
+      unpack_ew(Tn - 1, E1); ew_pre(E1, f); ew_post(Tn - 1, E1, f, E1.g);
     } else {
       load_ew(Tn - 1, E0);
       if (Tn >= 2) load_ew(Tn - 2, E1);
-      ew_pre(E0, f); ew_post(Tn - 1, E0, f, E0.g);
+      unpack_ew(Tn - 1, E0); ew_pre(E0, f); ew_post(Tn - 1, E0, f, E0.g);
     }
   }
   __syncthreads();
