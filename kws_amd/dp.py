@@ -47,6 +47,7 @@ class GradBucket:
         p0 = self.params[0]
         self.flat = torch.zeros(self.total, dtype=p0.dtype, device=p0.device)
         self.views = list(self.flat.split(self.sizes))
+        self._avg_ok = True
 
     def pack_(self):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
@@ -54,17 +55,28 @@ class GradBucket:
         return self.flat
 
     def unpack_(self):
+        missing = [p for p in self.params if p.grad is None]
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 p.grad = v.view_as(p).clone()
-            else:
-                p.grad.copy_(v.view_as(p))
+        if not missing:                       # the usual case: ONE fused copy kernel, like pack_()
+            torch._foreach_copy_([p.grad.view(-1) for p in self.params], self.views)
 
     def all_reduce_(self):
+        """pack (1 kernel) -> one collective -> unpack (1 kernel).  With the RCCL backend and the default
+        divisor the mean is taken inside the collective (ReduceOp.AVG), otherwise SUM + one scale."""
         self.pack_()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        if self.divisor != 1.0:
-            self.flat.mul_(1.0 / self.divisor)
+        avg_in_collective = (self._avg_ok and self.divisor == float(self.world) and self.world > 1
+                             and dist.get_backend(self.group) == "nccl")
+        if avg_in_collective:
+            try:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            except RuntimeError:              # a backend build without ncclAvg: fall back for good
+                self._avg_ok = avg_in_collective = False
+        if not avg_in_collective:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.divisor != 1.0:
+                self.flat.mul_(1.0 / self.divisor)
         self.unpack_()
         return self.flat
 
