@@ -604,3 +604,40 @@ def test_module_bf16_sequences_autograd():
         scale = max(1.0, float(p_.grad.abs().max()))
         # h_prev enters dU / d_zeta through its bf16-rounded copy: relative 2^-9 per term, random sign
         assert (gb[n] - p_.grad).abs().max() / scale <= 1e-2, n
+
+
+def test_grad_bucket_on_rccl_single_rank():
+    """The data-parallel exchange on the real backend (RCCL), one rank: the bucket's pack -> all-reduce ->
+    unpack leaves the gradients unchanged, on the compute stream, and ReduceOp.AVG -- which the N>1 path
+    uses to take the mean inside the collective -- is accepted by this RCCL build (else the bucket's
+    SUM + scale fallback is what will run)."""
+    import os
+    import torch.distributed as dist
+    from kws_amd.dp import GradBucket
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(2)
+        m = FastGRNNCUDA(32, 128, device=DEV)
+        x = torch.randn(9, 32, 32, device=DEV)
+        m(x).sum().backward()
+        before = [p_.grad.clone() for p_ in m.parameters()]
+        bucket = GradBucket(list(m.parameters()))
+        assert bucket.total == 128 * 32 + 128 * 128 + 2 * 128 + 2          # SURVEY 8e: 20 738 floats
+        bucket.all_reduce_()
+        torch.cuda.synchronize()
+        for a, p_ in zip(before, m.parameters()):
+            assert torch.equal(a, p_.grad)
+        t = torch.ones(4, device=DEV)
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            torch.cuda.synchronize()
+            assert torch.equal(t, torch.ones(4, device=DEV))
+        except RuntimeError:
+            pass                                  # GradBucket falls back to SUM + scale
+    finally:
+        if own_group:
+            dist.destroy_process_group()
