@@ -88,6 +88,9 @@ typedef enum fastgrnn_nonlinearity {
  * only -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the caller transposes as the reference
  * does.  Removes the transpose(0,1).contiguous() copies around the operator. */
 #define FASTGRNN_FLAG_BATCH_MAJOR 16u
+/* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
+ * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
+#define FASTGRNN_FLAG_FWD_BF16X3 64u
 /* A/B only: run the dense split-precision backward as the older 4-wave kernel instead of the 8-wave one. */
 #define FASTGRNN_FLAG_BWD_4WAVE 32u
 

@@ -128,6 +128,36 @@ __device__ __forceinline__ Frag3 split3(const f32x4 lo, const f32x4 hi) {
   return f;
 }
 
+// fp16 two-plane operands (forward state product only, see fwd_scan_split_w8): v = hi + lo with hi = fp16(v),
+// lo = fp16(v - hi): 22-23 significant bits while v is in fp16's normal range
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct Frag2h { u32x4 hi, lo; };
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {   // two values -> one dword per plane
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;                                       // round to nearest even
+  const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+  hi = __builtin_bit_cast(unsigned, f16x2{ha, hb});
+  lo = __builtin_bit_cast(unsigned, f16x2{la, lb});
+}
+__device__ __forceinline__ Frag2h split2h8(const f32x4 lo4, const f32x4 hi4) {
+  unsigned h[4], l[4];
+  split2h(lo4[0], lo4[1], h[0], l[0]); split2h(lo4[2], lo4[3], h[1], l[1]);
+  split2h(hi4[0], hi4[1], h[2], l[2]); split2h(hi4[2], hi4[3], h[3], l[3]);
+  Frag2h f;
+  f.hi = u32x4{h[0], h[1], h[2], h[3]}; f.lo = u32x4{l[0], l[1], l[2], l[3]};
+  return f;
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// acc += A.B with the three retained plane pairs (lo.lo, 2^-22 relative, dropped; small terms first)
+__device__ __forceinline__ f32x4 mfma3h(const Frag2h& a, const Frag2h& b, f32x4 acc) {
+  acc = mfma_f16(a.lo, b.hi, acc);
+  acc = mfma_f16(a.hi, b.lo, acc);
+  acc = mfma_f16(a.hi, b.hi, acc);
+  return acc;
+}
+
 // acc += sum over the six retained plane pairs of A[pa] . B[pb]   (small terms first)
 __device__ __forceinline__ f32x4 mfma6(const Frag3& a, const Frag3& b, f32x4 acc) {
   acc = mfma_bf16(a.p[2], b.p[0], acc);
@@ -316,7 +346,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
 constexpr int W8_ROWH = 272;            // bytes per utterance row of a 128-wide bf16 plane (256 + 16: conflict-free b128 reads)
 constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide bf16 plane (64 + 16)
 
-template <int GATE, int AUX, bool RAGGED, bool BF = false>
+template <int GATE, int AUX, bool RAGGED, bool BF = false, bool F16H = true>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -339,13 +369,38 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   const int xb = blockIdx.x * 16 + xu;
   const int xbc = (!RAGGED || xb < B) ? xb : B - 1;
 
+  // F16H: the state product U.h_{t-1} runs on fp16 two-plane operands (3 MFMAs per K-step instead of 6, two
+  // state planes through LDS instead of three).  h is bounded (|h| <= max(|h0|, sigma(zeta)+sigma(nu))), so
+  // its planes are always in fp16's range; U is pre-scaled per wave by an exact power of two that puts its
+  // largest element in [2^12, 2^13) (lo planes stay normal), undone by one fma in the epilogue.  W.x keeps
+  // the three bf16 planes: x is unbounded user data.  Measured error vs fp64 is that of an fp32 matmul.
   Frag3 Uf[KS], Wf;
+  Frag2h Uh[KS];
+  float u_unscale = 1.0f;
   {
     const int nA = wv * 16 + i;                    // A row i = unit 16w + i, K in natural unit order
+    f32x4 ulo[KS], uhi[KS];
+    float umax = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
       const float* up = u + (size_t)nA * H + 32 * s2 + 8 * g;
-      Uf[s2] = split3(ld4(up), ld4(up + 4));
+      ulo[s2] = ld4(up); uhi[s2] = ld4(up + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) umax = fmaxf(umax, fmaxf(fabsf(ulo[s2][j]), fabsf(uhi[s2][j])));
+    }
+    if (F16H) {
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) umax = fmaxf(umax, __shfl_xor(umax, m));
+      int e = 0;
+      if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &e);      // umax = f * 2^e, f in [0.5, 1)
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+      const float u_scale = ldexpf(1.0f, 13 - e);
+      u_unscale = ldexpf(1.0f, e - 13);
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) Uh[s2] = split2h8(ulo[s2] * u_scale, uhi[s2] * u_scale);
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) Uf[s2] = split3(ulo[s2], uhi[s2]);
     }
     const float* wp = w + (size_t)nA * F + 8 * g;
     Wf = split3(ld4(wp), ld4(wp + 4));
@@ -356,6 +411,14 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
 
   // planes of this lane's 4 state values -> 8 bytes per plane at [utterance i][unit n0]
   auto publish_h = [&](int buf) __attribute__((always_inline)) {
+    const unsigned off = i * W8_ROWH + n0 * 2;
+    if (F16H) {
+      uint2 hi, lo;
+      split2h(hown[0], hown[1], hi.x, lo.x); split2h(hown[2], hown[3], hi.y, lo.y);
+      *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = hi;
+      *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = lo;
+      return;
+    }
     unsigned b0[4], b1[4], b2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -365,7 +428,6 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
       const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
       b2[j] = fbits(r2);
     }
-    const unsigned off = i * W8_ROWH + n0 * 2;
     *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
     *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
     *reinterpret_cast<uint2*>(&hpl[buf][2][off]) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
@@ -409,13 +471,20 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     const float xpub = xnext;
     xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
     Frag3 xB, hB[KS];
+    Frag2h hH[KS];
 #pragma unroll
     for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(&xpl[cur][p][i * W8_ROWX + 16 * g]);
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2)
+    for (int s2 = 0; s2 < KS; ++s2) {
+      if (F16H) {
+        hH[s2].hi = *reinterpret_cast<const u32x4*>(&hpl[cur][0][i * W8_ROWH + 64 * s2 + 16 * g]);
+        hH[s2].lo = *reinterpret_cast<const u32x4*>(&hpl[cur][1][i * W8_ROWH + 64 * s2 + 16 * g]);
+      } else {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        hB[s2].p[p] = *reinterpret_cast<const u32x4*>(&hpl[cur][p][i * W8_ROWH + 64 * s2 + 16 * g]);
+        for (int p = 0; p < 3; ++p)
+          hB[s2].p[p] = *reinterpret_cast<const u32x4*>(&hpl[cur][p][i * W8_ROWH + 64 * s2 + 16 * g]);
+      }
+    }
     if (t > 0) store_step(t - 1, aux_prev);          // h_{t-1} and its pre-activation: issued during the LDS round trip
     publish_x(cur ^ 1, xpub);
     // every fragment read is ISSUED -- so each has registers of its own -- before the first MFMA that reads
@@ -424,8 +493,15 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
     f32x4 a = mfma6(Wf, xB, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (F16H) {
+      f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) a = mfma6(Uf[s2], hB[s2], a);                        // .cu:368
+      for (int s2 = 0; s2 < KS; ++s2) ah = mfma3h(Uh[s2], hH[s2], ah);                   // .cu:368, scaled by 2^k
+      a += ah * u_unscale;
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) a = mfma6(Uf[s2], hB[s2], a);                      // .cu:368
+    }
     f32x4 zq, cq;
     SPLIT_STAMP(2)
 #pragma unroll
@@ -1913,6 +1989,13 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
     block = dim3(512);
     if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, true>); else go(fwd_scan_split_w8<GATE, 2, false, true>); }
     else          { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, true>); else go(fwd_scan_split_w8<GATE, 0, false, true>); }
+    return;
+  }
+  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // A/B: state product on 3 bf16 planes
+    block = dim3(512);
+    if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true, false, false>); else go(fwd_scan_split_w8<GATE, 1, false, false, false>); }
+    else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, false, false>); else go(fwd_scan_split_w8<GATE, 2, false, false, false>); }
+    else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, false, false>); else go(fwd_scan_split_w8<GATE, 0, false, false, false>); }
     return;
   }
   if (!(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {        // default: the 8-wave shape
