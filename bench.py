@@ -137,21 +137,23 @@ def main():
                                        else "z_s/h_prime_s saved as the reference operator does"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernel_path": {"forward": path_f, "backward": path_b}},
-            # dominant kernel = the backward scan (fastgrnn_hip_backward_unroll); the scan's
-            # binding roof at fp32 is the f32 MFMA/FMA rate (intensity ~64 flop/B)
-            # dominant kernel = the backward scan (fastgrnn_hip_backward_unroll).  Its algorithmic work is
-            # fp32: achieved = algorithmic fp32 FLOP / launch time against the fp32 MFMA (= fp32 vector)
-            # peak.  On kernel path 2 every fp32 product is executed as 6 bf16 MFMA terms on the bf16
-            # matrix pipe; "executed" prices those against the dense bf16 peak.
-            "roofline": {"kernel": "backward_unroll", "bound": "mfma", "achieved": tf_b, "peak": PEAK_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf_b / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": avg_b, "flops_per_launch": B * FLOPS_BWD,
-                         "executed": ({"dtype": "bf16 x3 planes, 6 terms", "tflops": 6 * tf_b,
-                                       "peak": PEAK_BF16_TFLOPS, "frac": 6 * tf_b / PEAK_BF16_TFLOPS} if split else None)},
-            "roofline_hbm": {"kernel": "backward_unroll", "bound": "hbm",
-                             "achieved": B * BYTES_BWD / (avg_b * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
-                             "moved_gbs": (B * BYTES_BWD_PREACT / (avg_b * 1e-3) / 1e9) if split else None},
+            # Dominant kernel = the backward scan (fastgrnn_hip_backward_unroll).  SURVEY 8d designates HBM
+            # bandwidth as the roof of the scan: achieved = algorithmic bytes per launch (126 720 B per
+            # utterance: read grad_hs, hs, x; write d_x) / average launch time measured with events on the launch
+            # stream inside the timed region; traffic = the PMC byte count of profiles/traffic.json; moved_gbs
+            # prices the bytes the one-saved-tensor autograd path really moves.  The kernel is NOT HBM-bound:
+            # roofline_mfma gives the matrix-pipe view -- algorithmic fp32 FLOP against the fp32 MFMA (= fp32
+            # vector) peak, and "executed": every fp32 product is issued as 6 bf16 MFMA terms, priced against the
+            # dense bf16 peak.  What binds is the SIMD's VALU-type issue slot.
+            "roofline": {"kernel": "backward_unroll", "bound": "hbm",
+                         "achieved": B * BYTES_BWD / (avg_b * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_b, "bytes_per_launch": B * BYTES_BWD,
+                         "moved_gbs": (B * BYTES_BWD_PREACT / (avg_b * 1e-3) / 1e9) if split else None},
+            "roofline_mfma": {"kernel": "backward_unroll", "bound": "mfma", "achieved": tf_b, "peak": PEAK_F32_TFLOPS,
+                              "unit": "TFLOP/s", "frac": tf_b / PEAK_F32_TFLOPS, "flops_per_launch": B * FLOPS_BWD,
+                              "executed": ({"dtype": "bf16 x3 planes, 6 terms", "tflops": 6 * tf_b,
+                                            "peak": PEAK_BF16_TFLOPS, "frac": 6 * tf_b / PEAK_BF16_TFLOPS} if split else None)},
             "forward_kernel": {"avg_launch_ms": avg_f, "tflops": tf_f, "frac_f32_peak": tf_f / PEAK_F32_TFLOPS,
                                "hbm_gbs": B * BYTES_FWD / (avg_f * 1e-3) / 1e9},
         }
