@@ -24,7 +24,8 @@
  *     (.cu:148-149,364-365) and d_zeta/d_nu are w.r.t. the raw values
  *     (.cu:116-117).
  *   - gate code table {sigmoid:0, relu:1, tanh:2} is rnn.py:478,751; codes 3..5
- *     add the CPU cell's quantTanh/quantSigm/quantSigm4 (rnn.py:53-60).  The
+ *     add the CPU cell's quantTanh/quantSigm/quantSigm4 (rnn.py:53-60; kernel path 2 under
+ *     FASTGRNN_FLAG_SAVE_PREACT for the dense H=128/F=32 shape, the generic scan otherwise).  The
  *     reference's CUDA path fixes the update nonlinearity to tanh (.cu:57);
  *     update_nl is exposed because the CPU cell allows it (rnn.py:292-293).
  *   - every function returns a fastgrnn_status; nonzero means nothing useful

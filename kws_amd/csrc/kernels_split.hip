@@ -37,14 +37,23 @@ __device__ __forceinline__ float fsigmoid(float a) {
 __device__ __forceinline__ float ftanh(float a) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * a));
 }
+// gate nonlinearities: the reference's GPU table {sigmoid, relu, tanh} (rnn.py:478) and, on the 8-wave dense
+// kernels, the CPU cell's quantised family (rnn.py:53-60); derivatives through the output as in
+// common.h / .cu:27-40
 template <int GATE> __device__ __forceinline__ float gate_act(float a) {
   if (GATE == FASTGRNN_NL_SIGMOID) return fsigmoid(a);
   if (GATE == FASTGRNN_NL_RELU) return a > 0.0f ? a : 0.0f;
+  if (GATE == FASTGRNN_NL_QUANT_TANH) return fminf(fmaxf(a, -1.0f), 1.0f);
+  if (GATE == FASTGRNN_NL_QUANT_SIGM) return fminf(fmaxf((a + 1.0f) * 0.5f, 0.0f), 1.0f);
+  if (GATE == FASTGRNN_NL_QUANT_SIGM4) return fminf(fmaxf((a + 2.0f) * 0.25f, 0.0f), 1.0f);
   return ftanh(a);
 }
 template <int GATE> __device__ __forceinline__ float gate_dact(float y) {
   if (GATE == FASTGRNN_NL_SIGMOID) return (1.0f - y) * y;
   if (GATE == FASTGRNN_NL_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (GATE == FASTGRNN_NL_QUANT_TANH) return (y < 1.0f && y > -1.0f) ? 1.0f : 0.0f;
+  if (GATE == FASTGRNN_NL_QUANT_SIGM) return (y < 1.0f && y > 0.0f) ? 0.5f : 0.0f;
+  if (GATE == FASTGRNN_NL_QUANT_SIGM4) return (y < 1.0f && y > 0.0f) ? 0.25f : 0.0f;
   return 1.0f - y * y;
 }
 
@@ -1536,9 +1545,11 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   if (d.dtype == FASTGRNN_BF16_IO) {
     block = dim3(512);
     if (ragged) go(bwd_scan_split_w8<GATE, true, true, true>); else go(bwd_scan_split_w8<GATE, true, false, true>);
-  } else if ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact) {
-    if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
-    else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
+  } else if (GATE <= FASTGRNN_NL_TANH && ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact)) {
+    if constexpr (GATE <= FASTGRNN_NL_TANH) {
+      if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
+      else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
+    }
   } else {
     block = dim3(512);
     if (ragged) go(bwd_scan_split_w8<GATE, true, true>); else go(bwd_scan_split_w8<GATE, true, false>);
@@ -1991,23 +2002,25 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
     else          { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, true>); else go(fwd_scan_split_w8<GATE, 0, false, true>); }
     return;
   }
-  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // A/B: state product on 3 bf16 planes
+  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
     block = dim3(512);
     if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true, false, false>); else go(fwd_scan_split_w8<GATE, 1, false, false, false>); }
     else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, false, false>); else go(fwd_scan_split_w8<GATE, 2, false, false, false>); }
     else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, false, false>); else go(fwd_scan_split_w8<GATE, 0, false, false, false>); }
     return;
   }
-  if (!(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {        // default: the 8-wave shape
+  if (GATE > FASTGRNN_NL_TANH || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
     block = dim3(512);
     if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true>); else go(fwd_scan_split_w8<GATE, 1, false>); }
     else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true>); else go(fwd_scan_split_w8<GATE, 2, false>); }
     else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true>); else go(fwd_scan_split_w8<GATE, 0, false>); }
     return;
   }
-  if (aux == 1)      { if (ragged) go(fwd_scan_split<GATE, 1, true>); else go(fwd_scan_split<GATE, 1, false>); }
-  else if (aux == 2) { if (ragged) go(fwd_scan_split<GATE, 2, true>); else go(fwd_scan_split<GATE, 2, false>); }
-  else               { if (ragged) go(fwd_scan_split<GATE, 0, true>); else go(fwd_scan_split<GATE, 0, false>); }
+  if constexpr (GATE <= FASTGRNN_NL_TANH) {          // the 4-wave kernel knows the reference's three gates only
+    if (aux == 1)      { if (ragged) go(fwd_scan_split<GATE, 1, true>); else go(fwd_scan_split<GATE, 1, false>); }
+    else if (aux == 2) { if (ragged) go(fwd_scan_split<GATE, 2, true>); else go(fwd_scan_split<GATE, 2, false>); }
+    else               { if (ragged) go(fwd_scan_split<GATE, 0, true>); else go(fwd_scan_split<GATE, 0, false>); }
+  }
 }
 
 template <int GATE>
@@ -2035,15 +2048,17 @@ bool lowrank_fwd_shape(const fastgrnn_desc& d) {
 
 bool split_supported(const fastgrnn_desc& d, int direction) {
   if ((d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO) || d.update_nl != FASTGRNN_NL_TANH ||
-      d.gate_nl < FASTGRNN_NL_SIGMOID || d.gate_nl > FASTGRNN_NL_TANH)
+      d.gate_nl < FASTGRNN_NL_SIGMOID || d.gate_nl > FASTGRNN_NL_QUANT_SIGM4)
     return false;
   const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32;
+  const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  // quantised gates (rnn.py:53-60): 8-wave dense kernels only, i.e. the backward under the SAVE_PREACT contract
+  if (d.gate_nl > FASTGRNN_NL_TANH) return dense && (direction == 0 || preact);
   // bf16 sequences: dense shape only; the backward only under the SAVE_PREACT contract (8-wave kernel)
-  if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0);
+  if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || preact);
   // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style
   // backward with z_s / h_prime_s stays on the generic scan)
-  if (lowrank_fwd_shape(d))
-    return !(d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0);
+  if (lowrank_fwd_shape(d)) return !(d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (direction == 0 || preact);
   return dense;
 }
 
@@ -2067,7 +2082,10 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
-    default: launch_bwd_gate<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_TANH: launch_bwd_gate<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_QUANT_TANH: launch_bwd_gate<FASTGRNN_NL_QUANT_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_QUANT_SIGM: launch_bwd_gate<FASTGRNN_NL_QUANT_SIGM>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    default: launch_bwd_gate<FASTGRNN_NL_QUANT_SIGM4>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
   }
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
@@ -2088,7 +2106,10 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_fwd_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
     case FASTGRNN_NL_RELU: launch_fwd_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;
-    default: launch_fwd_gate<FASTGRNN_NL_TANH>(d, p, x, h0, hs, zs, cs, s); break;
+    case FASTGRNN_NL_TANH: launch_fwd_gate<FASTGRNN_NL_TANH>(d, p, x, h0, hs, zs, cs, s); break;
+    case FASTGRNN_NL_QUANT_TANH: launch_fwd_gate<FASTGRNN_NL_QUANT_TANH>(d, p, x, h0, hs, zs, cs, s); break;
+    case FASTGRNN_NL_QUANT_SIGM: launch_fwd_gate<FASTGRNN_NL_QUANT_SIGM>(d, p, x, h0, hs, zs, cs, s); break;
+    default: launch_fwd_gate<FASTGRNN_NL_QUANT_SIGM4>(d, p, x, h0, hs, zs, cs, s); break;
   }
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }

@@ -641,3 +641,44 @@ def test_grad_bucket_on_rccl_single_rank():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gate", ["quantTanh", "quantSigm", "quantSigm4"])
+def test_quantised_gates_on_the_matrix_pipe(gate):
+    """the CPU cell's quantised gate nonlinearities (rnn.py:53-60) on the 8-wave split-precision
+    kernels (one-saved-tensor contract).  Piecewise-linear gates have derivative jumps, so -- as for relu --
+    the backward is compared with the oracle evaluated on the kernel's own gate values (same mask)."""
+    T, B, F, H = 12, 37, 32, 128
+    SAVE_PREACT = 4
+    code = GATE_CODE[gate]
+    rng = np.random.default_rng(code)
+    p = O.make_params(F, H, dtype=np.float32, seed=31, randomize_scalars=True)
+    p["bias_gate"] = (0.3 * p["bias_gate"]).astype(np.float32)   # pre-activations on both sides of the clamps
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    P = _param_tensors(p)
+    xt, ht, Gt = _t(x), _t(h0), _t(G)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, direction=0, flags=SAVE_PREACT) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, direction=1, flags=SAVE_PREACT) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, direction=1) != 2     # reference contract: generic scan
+    hs, pre = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                           code, P["w1"], P["w2"], P["u1"], P["u2"], flags=SAVE_PREACT)
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], code, flags=SAVE_PREACT,
+                                         bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
+    assert (np.abs(hs.cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    # a fair share of the gate values is strictly inside (0,1) / (-1,1): the test exercises both branches
+    inside = (zs_o > (-1 if gate == "quantTanh" else 0)) & (zs_o < 1)
+    assert 0.2 < inside.mean() < 0.999, inside.mean()
+    pre_k = pre.cpu().numpy()
+    a = pre_k + p["bias_gate"]
+    zk = {"quantTanh": np.clip(a, -1, 1), "quantSigm": np.clip((a + 1) / 2, 0, 1),
+          "quantSigm4": np.clip((a + 2) / 4, 0, 1)}[gate].astype(np.float32)
+    ck = np.tanh(pre_k + p["bias_update"]).astype(np.float32)
+    g_o = O.unroll_backward(G, x, hs.cpu().numpy(), zk, ck, p, h0, gate=gate)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+    g = {n: o.cpu().numpy() for n, o in zip(names, outs[:8])}
+    _check_grads(g, g_o, 5e-5, gate)
