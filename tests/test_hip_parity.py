@@ -92,6 +92,9 @@ CASES = [
     (5, 5, 13, 24, 4, 0, "relu"),
     (3, 1, 1, 1, 0, 0, "sigmoid"),          # degenerate sizes
     (1, 7, 32, 128, 0, 0, "sigmoid"),       # T = 1
+    (2, 1, 32, 128, 0, 0, "sigmoid"),       # one utterance, even T (no virtual pairing step)
+    (3, 16, 32, 128, 0, 0, "tanh"),         # exactly one full tile, odd T
+    (2, 17, 32, 256, 16, 16, "sigmoid"),    # low-rank kernels: ragged second tile, T = 2
 ]
 
 
@@ -141,7 +144,7 @@ def test_seeded_vs_oracle_fp64(lowrank):
     _check_grads(g, g_o, 1e-10, "fp64")
 
 
-@pytest.mark.parametrize("B", [64, 45])
+@pytest.mark.parametrize("B", [64, 45, 1, 16])
 def test_preact_mode_vs_oracle(B):
     """FLAG_SAVE_PREACT (kernel path 2): forward saves W.x+U.h only; backward recomputes z, h_prime."""
     T, F, H = 99, 32, 128
@@ -487,7 +490,7 @@ def test_run_to_run_bitwise_repeatability():
                     assert torch.equal(a, b), (H, r, rep, k)
 
 
-@pytest.mark.parametrize("B,preact", [(37, True), (64, True), (48, False)])
+@pytest.mark.parametrize("B,preact", [(37, True), (64, True), (48, False), (1, True)])
 def test_batch_major_layout_equals_time_major(B, preact):
     """FLAG_BATCH_MAJOR (N1: the trainer's batch_first layout indexed in place, rnn.py:812-813,823-825):
     same arithmetic per utterance, so every output equals the time-major run bit for bit."""
