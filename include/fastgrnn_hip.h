@@ -89,6 +89,11 @@ typedef enum fastgrnn_nonlinearity {
  * only -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the caller transposes as the reference
  * does.  Removes the transpose(0,1).contiguous() copies around the operator. */
 #define FASTGRNN_FLAG_BATCH_MAJOR 16u
+/* x and d_x are [B,F,T]: what the trainer's data loader delivers and permute(2,0,1)s into a [T,B,F] VIEW
+ * (trainClassifier.py:204,299) that the reference then copies with .contiguous() (rnn.py:910).  Independent
+ * of FASTGRNN_FLAG_BATCH_MAJOR (which then only governs hs, the saved tensor and grad_hs).  Kernel path 2,
+ * dense H=128/F=32, 8-wave kernels (forward; backward under FASTGRNN_FLAG_SAVE_PREACT). */
+#define FASTGRNN_FLAG_X_BFT 128u
 /* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
  * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
 #define FASTGRNN_FLAG_FWD_BF16X3 64u

@@ -91,7 +91,7 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   if (!x || !h0 || !hs) return FASTGRNN_ERR_NULL_POINTER;
-  if (((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR)) || d->dtype == FASTGRNN_BF16_IO) &&
+  if (((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) || d->dtype == FASTGRNN_BF16_IO) &&
       pick_path(d, 0) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_forward_workspace_bytes(d)))) return st;
@@ -110,7 +110,7 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   const bool preact = (d->flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  if ((preact || (d->flags & FASTGRNN_FLAG_BATCH_MAJOR) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
+  if ((preact || (d->flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if (!grad_hs || !x || !hs || !z_s || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
   if (!g->d_x || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)

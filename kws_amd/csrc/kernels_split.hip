@@ -357,7 +357,7 @@ constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide 
 
 template <int GATE, int AUX, bool RAGGED, bool BF = false, bool F16H = true>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
-    int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
+    int Tn, int B, int rsT, int rsB, int xbft, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
@@ -452,8 +452,12 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     *reinterpret_cast<unsigned short*>(&xpl[buf][1][off]) = (unsigned short)(a1 >> 16);
     *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = (unsigned short)(a2 >> 16);
   };
+  // x is [T,B,F] / [B,T,F] (rsT, rsB) or, with FASTGRNN_FLAG_X_BFT, the trainer's [B,F,T]: this lane's value of
+  // frame t is x[xbase + t * xstep]
+  const size_t xbase = xbft ? ((size_t)xbc * F + xf) * Tn : (size_t)xbc * rsB * F + xf;
+  const size_t xstep = xbft ? 1 : (size_t)rsT * F;
   auto load_x = [&](int t) __attribute__((always_inline)) {
-    const size_t e = ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
+    const size_t e = xbase + (size_t)t * xstep;
     return BF ? bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[e]) : x[e];
   };
   auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
@@ -1137,7 +1141,7 @@ struct BwdW8Lds {
 
 template <int GATE, bool PREACT, bool RAGGED, bool BF = false>
 __global__ __launch_bounds__(512) void bwd_scan_split_w8(
-    int Tn, int B, int rsT, int rsB, const float* __restrict__ ghs, const float* __restrict__ x,
+    int Tn, int B, int rsT, int rsB, int xbft, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
     const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
@@ -1222,7 +1226,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
     e.a0 = ld4(aux0 + o);
     if (!PREACT) e.a1 = ld4(aux1 + o);
-    const size_t ex = ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
+    const size_t ex = xbft ? ((size_t)xbc * F + xf) * Tn + t : ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
     if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
       e.graw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + o);
       e.hraw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(hs) + (t == 0 ? o : o - (size_t)rsT * H));
@@ -1317,8 +1321,19 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   auto finish_dx = [&](int t) __attribute__((always_inline)) {
     if (wv < NFT) {                         // wave-uniform: feature tile wv = sum over the four K-steps
       const f32x4 sacc = (S.DX[t & 1][wv][l] + S.DX[t & 1][wv + 2][l]) + (S.DX[t & 1][wv + 4][l] + S.DX[t & 1][wv + 6][l]);
-      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g;
-      if (valid) { if (BF) st4_bf16(reinterpret_cast<unsigned short*>(d_x) + o, sacc); else st4(d_x + o, sacc); }
+      if (xbft) {                                    // d_x in the trainer's [B,F,T]: features are T apart
+        if (valid) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const size_t o = ((size_t)b * F + wv * 16 + 4 * g + r) * Tn + t;
+            if (BF) reinterpret_cast<unsigned short*>(d_x)[o] = (unsigned short)f32_to_bf16_rne(sacc[r]);
+            else d_x[o] = sacc[r];
+          }
+        }
+      } else {
+        const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g;
+        if (valid) { if (BF) st4_bf16(reinterpret_cast<unsigned short*>(d_x) + o, sacc); else st4(d_x + o, sacc); }
+      }
     }
   };
   // dW += d_pre_s^T x_s, dU += d_pre_s^T h_{s-1} (.cu:539-540) for the step pair (sU, sU-1): this wave's
@@ -1540,19 +1555,27 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
   };
+  auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
+    hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
+                       (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)ghs,
+                       (const float*)x, (const float*)hs,
+                       (const float*)a0, (const float*)a1, (const float*)h0, (const float*)p.w, (const float*)p.u,
+                       (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
+                       (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
+  };
   // 8-wave kernel for the one-saved-tensor contract (9-11 % faster in the same run); with the reference
   // operator's (z_s, h_prime_s) pair its extra operand set costs more registers than it gains
   if (d.dtype == FASTGRNN_BF16_IO) {
     block = dim3(512);
-    if (ragged) go(bwd_scan_split_w8<GATE, true, true, true>); else go(bwd_scan_split_w8<GATE, true, false, true>);
-  } else if (GATE <= FASTGRNN_NL_TANH && ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact)) {
+    if (ragged) go8(bwd_scan_split_w8<GATE, true, true, true>); else go8(bwd_scan_split_w8<GATE, true, false, true>);
+  } else if (GATE <= FASTGRNN_NL_TANH && !(d.flags & FASTGRNN_FLAG_X_BFT) && ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact)) {
     if constexpr (GATE <= FASTGRNN_NL_TANH) {
       if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
       else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
     }
   } else {
     block = dim3(512);
-    if (ragged) go(bwd_scan_split_w8<GATE, true, true>); else go(bwd_scan_split_w8<GATE, true, false>);
+    if (ragged) go8(bwd_scan_split_w8<GATE, true, true>); else go8(bwd_scan_split_w8<GATE, true, false>);
   }
   const int ntot = 128 * 128 + 128 * 32 + 2 * 128 + 2;
   hipLaunchKernelGGL(reduce_slabs_split, dim3((ntot + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
@@ -1996,24 +2019,30 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
+    hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
+                       (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)x, (const float*)h0, (const float*)p.w,
+                       (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
+                       (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
+  };
   if (d.dtype == FASTGRNN_BF16_IO) {                 // bf16 sequences: 8-wave kernel, hs only or hs + pre-activation
     block = dim3(512);
-    if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, true>); else go(fwd_scan_split_w8<GATE, 2, false, true>); }
-    else          { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, true>); else go(fwd_scan_split_w8<GATE, 0, false, true>); }
+    if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, true>); else go8(fwd_scan_split_w8<GATE, 2, false, true>); }
+    else          { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, true>); else go8(fwd_scan_split_w8<GATE, 0, false, true>); }
     return;
   }
-  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
+  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
     block = dim3(512);
-    if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true, false, false>); else go(fwd_scan_split_w8<GATE, 1, false, false, false>); }
-    else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true, false, false>); else go(fwd_scan_split_w8<GATE, 2, false, false, false>); }
-    else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true, false, false>); else go(fwd_scan_split_w8<GATE, 0, false, false, false>); }
+    if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true, false, false>); else go8(fwd_scan_split_w8<GATE, 1, false, false, false>); }
+    else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, false, false>); else go8(fwd_scan_split_w8<GATE, 2, false, false, false>); }
+    else               { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, false, false>); else go8(fwd_scan_split_w8<GATE, 0, false, false, false>); }
     return;
   }
-  if (GATE > FASTGRNN_NL_TANH || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
+  if (GATE > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
     block = dim3(512);
-    if (aux == 1)      { if (ragged) go(fwd_scan_split_w8<GATE, 1, true>); else go(fwd_scan_split_w8<GATE, 1, false>); }
-    else if (aux == 2) { if (ragged) go(fwd_scan_split_w8<GATE, 2, true>); else go(fwd_scan_split_w8<GATE, 2, false>); }
-    else               { if (ragged) go(fwd_scan_split_w8<GATE, 0, true>); else go(fwd_scan_split_w8<GATE, 0, false>); }
+    if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true>); else go8(fwd_scan_split_w8<GATE, 1, false>); }
+    else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true>); else go8(fwd_scan_split_w8<GATE, 2, false>); }
+    else               { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true>); else go8(fwd_scan_split_w8<GATE, 0, false>); }
     return;
   }
   if constexpr (GATE <= FASTGRNN_NL_TANH) {          // the 4-wave kernel knows the reference's three gates only
@@ -2052,8 +2081,9 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
     return false;
   const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32;
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  // quantised gates (rnn.py:53-60): 8-wave dense kernels only, i.e. the backward under the SAVE_PREACT contract
-  if (d.gate_nl > FASTGRNN_NL_TANH) return dense && (direction == 0 || preact);
+  // quantised gates (rnn.py:53-60) and the [B,F,T] input layout: 8-wave dense kernels only, i.e. the backward
+  // under the SAVE_PREACT contract
+  if (d.gate_nl > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT)) return dense && (direction == 0 || preact);
   // bf16 sequences: dense shape only; the backward only under the SAVE_PREACT contract (8-wave kernel)
   if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || preact);
   // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style

@@ -150,7 +150,9 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     if unrolled:
         if input.dim() != 3:
             raise RuntimeError("input must be [timesteps, batch, features]")
-        if batch_major:
+        if flags & _lib.FLAG_X_BFT:          # the trainer's [B,F,T] (trainClassifier.py:204)
+            B, F, T = input.shape
+        elif batch_major:
             B, T, F = input.shape
         else:
             T, B, F = input.shape
@@ -210,12 +212,14 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
         _check_input(t, n)
     if unrolled:
-        if flags & _lib.FLAG_BATCH_MAJOR:
+        if flags & _lib.FLAG_X_BFT:
+            B, F, T = input.shape
+        elif flags & _lib.FLAG_BATCH_MAJOR:
             B, T, F = input.shape
         else:
             T, B, F = input.shape
         H = grad_h.shape[-1]
-        lead = tuple(input.shape[:2])
+        lead = (B, T) if flags & _lib.FLAG_BATCH_MAJOR else (T, B)
         _expect(grad_h, lead + (H,), "grad_h"); _expect(hs_or_old_h, lead + (H,), "hidden_states")
         _expect(z, lead + (H,), "z"); _expect(h_prime, lead + (H,), "h_prime"); _expect(h0, (B, H), "initial_h")
     else:

@@ -71,7 +71,6 @@ class FastGRNNUnrollFunction(Function):
                 batch_major=False):
         """``batch_major`` (not in the reference signature): ``input`` / the result are [B,T,.] and the
         kernels index them in place (FLAG_BATCH_MAJOR) instead of working on transposed copies."""
-        input = input.contiguous()
         old_h = old_h.contiguous()
         if batch_major:
             B, T, F = input.shape
@@ -80,12 +79,23 @@ class FastGRNNUnrollFunction(Function):
         H = old_h.shape[1]
         rw = w1.shape[0] if w1.numel() else 0
         ru = u1.shape[0] if u1.numel() else 0
+        # The trainer hands over permute(2,0,1) of the loader's [B,F,T] batch (trainClassifier.py:204,299), a
+        # [T,B,F] VIEW; the reference copies it here with .contiguous().  Where the kernels can read [B,F,T]
+        # in place (FLAG_X_BFT) the view's base is passed instead and d_input comes back as the same view.
+        x_bft = (not batch_major and input.is_cuda and not input.is_contiguous()
+                 and input.permute(1, 2, 0).is_contiguous()
+                 and input.dtype in (torch.float32, torch.bfloat16)
+                 and fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
+                                               _lib.FLAG_SAVE_PREACT | _lib.FLAG_X_BFT) == 2)
+        input = input.permute(1, 2, 0) if x_bft else input.contiguous()
         preact = (input.dtype in (torch.float32, torch.bfloat16) and input.is_cuda and
                   fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
                                             _lib.FLAG_SAVE_PREACT) == 2)
         flags = _lib.FLAG_SAVE_PREACT if preact else 0
         if batch_major:
             flags |= _lib.FLAG_BATCH_MAJOR
+        if x_bft:
+            flags |= _lib.FLAG_X_BFT
         ctx.flags = flags
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
                                                gate_non_linearity, w1, w2, u1, u2, flags=flags)
@@ -116,6 +126,8 @@ class FastGRNNUnrollFunction(Function):
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     z_s, h_prime_s, old_h, w1, w2, u1, u2,
                                                     ctx.gate_non_linearity, flags=ctx.flags)
+        if ctx.flags & _lib.FLAG_X_BFT:                 # d_input was produced as [B,F,T]: hand back the [T,B,F] view
+            outputs = [outputs[0].permute(2, 0, 1)] + list(outputs[1:])
         return _as_autograd_grads(outputs, ctx.needs_input_grad) + (None,)
 
 

@@ -685,3 +685,62 @@ def test_quantised_gates_on_the_matrix_pipe(gate):
     names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
     g = {n: o.cpu().numpy() for n, o in zip(names, outs[:8])}
     _check_grads(g, g_o, 5e-5, gate)
+
+
+@pytest.mark.parametrize("B,hs_batch_major", [(37, False), (64, False), (48, True)])
+def test_trainer_bft_input_layout_in_place(B, hs_batch_major):
+    """FLAG_X_BFT: x / d_x in the data loader's [B,F,T] (trainClassifier.py:204 permutes it into
+    a [T,B,F] view and the reference then copies it).  Same arithmetic: every output equals the time-major
+    run bit for bit."""
+    T, F, H = 23, 32, 128
+    SAVE_PREACT, BATCH_MAJOR, X_BFT = 4, 16, 128
+    p = O.make_params(F, H, seed=6, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+
+    def run(xi, Gi, flags):
+        outs = fastgrnn_cuda.forward_unroll(xi, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"],
+                                            h0, 0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+        gr = fastgrnn_cuda.backward_unroll(Gi, xi, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1], h0,
+                                           P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags, **kw)
+        return list(outs), list(gr)
+
+    o_t, g_t = run(x, G, SAVE_PREACT)
+    x_bft = x.permute(1, 2, 0).contiguous()                       # [B,F,T]
+    lay = (lambda t: t.transpose(0, 1).contiguous()) if hs_batch_major else (lambda t: t)
+    unlay = (lambda t: t.transpose(0, 1)) if hs_batch_major else (lambda t: t)
+    fl = SAVE_PREACT | X_BFT | (BATCH_MAJOR if hs_batch_major else 0)
+    o_b, g_b = run(x_bft, lay(G), fl)
+    for a, b in zip(o_t, o_b):
+        assert torch.equal(a, unlay(b))
+    assert g_b[0].shape == (B, F, T) and torch.equal(g_t[0], g_b[0].permute(2, 0, 1))
+    for a, b in zip(g_t[1:8], g_b[1:8]):
+        assert torch.equal(a, b)
+    # not offered off the 8-wave dense kernels
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=X_BFT) != 2
+
+
+def test_module_takes_the_trainers_permuted_view():
+    """FastGRNNCUDA fed `audio.permute(2, 0, 1)` exactly as trainClassifier.py:204 does: same results and the
+    same gradient on the loader's [B,F,T] tensor as with a contiguous copy, without making one."""
+    T, B, F, H = 29, 40, 32, 128
+    torch.manual_seed(8)
+    m = FastGRNNCUDA(F, H, device=DEV)
+    audio = torch.randn(B, F, T, device=DEV)
+    G = torch.randn(T, B, H, device=DEV)
+    a1 = audio.clone().requires_grad_(True)
+    hs1 = m(a1.permute(2, 0, 1))                                  # the trainer's view
+    hs1.backward(G)
+    g1 = {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+    for p_ in m.parameters():
+        p_.grad = None
+    a2 = audio.clone().requires_grad_(True)
+    hs2 = m(a2.permute(2, 0, 1).contiguous())                     # what the reference's .contiguous() makes
+    hs2.backward(G)
+    assert torch.equal(hs1, hs2) and torch.equal(a1.grad, a2.grad)
+    for n, p_ in m.named_parameters():
+        assert torch.equal(g1[n], p_.grad), n

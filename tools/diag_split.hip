@@ -58,7 +58,7 @@ void run_bwd_w8(int T, int B) {
   std::vector<float> ts;
   for (int rep = 0; rep < 10; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((bwd_scan_split_w8<0, PREACT, false>), dim3((B + 15) / 16), dim3(512), 0, 0, T, B, B, 1, ghs, x, hs, a0, a1,
+    hipLaunchKernelGGL((bwd_scan_split_w8<0, PREACT, false>), dim3((B + 15) / 16), dim3(512), 0, 0, T, B, B, 1, 0, ghs, x, hs, a0, a1,
                        h0, w, u, bz, bh, zeta, nu, dx, dh0, part);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -118,7 +118,7 @@ void run_fwd_w8(int T, int B) {
   std::vector<float> ts;
   for (int rep = 0; rep < 10; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((fwd_scan_split_w8<0, AUX, false>), dim3((B + 15) / 16), dim3(512), 0, 0, T, B, B, 1, x, h0, w, u, bz, bh,
+    hipLaunchKernelGGL((fwd_scan_split_w8<0, AUX, false>), dim3((B + 15) / 16), dim3(512), 0, 0, T, B, B, 1, 0, x, h0, w, u, bz, bh,
                        zeta, nu, hs, zs, cs);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
