@@ -4,8 +4,9 @@ cuda/fastgrnn_cuda.cpp:235-240).  HIP kernels + C ABI live in ``kws_amd/csrc``;
 there is no CPU path in this package."""
 from . import _lib  # noqa: F401
 from . import fastgrnn_cuda  # noqa: F401
+from . import utils  # noqa: F401
 from .rnn import (FastGRNNCUDA, FastGRNNCUDACell, FastGRNNFunction,  # noqa: F401
                   FastGRNNUnrollFunction)
 
-__all__ = ["fastgrnn_cuda", "FastGRNNCUDA", "FastGRNNCUDACell", "FastGRNNFunction",
+__all__ = ["fastgrnn_cuda", "utils", "FastGRNNCUDA", "FastGRNNCUDACell", "FastGRNNFunction",
            "FastGRNNUnrollFunction"]

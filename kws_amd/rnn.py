@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import _lib, fastgrnn_cuda
+from . import _lib, fastgrnn_cuda, utils
 
 NON_LINEARITY = {"sigmoid": 0, "relu": 1, "tanh": 2}   # rnn.py:478,751
 
@@ -180,6 +180,51 @@ def _get_vars(mod):
     return Vars
 
 
+# ---- sparsification bookkeeping (rnn.py:843-889), all on the parameters' device ----------
+def _get_model_size(mod):
+    """rnn.py:843-865: 4 bytes x (non-zeros of the W/U matrices when their sparsity flag is set, else their
+    sizes) + biases + zeta, nu.  The reference counts on CPU copies; ``isSparse`` is the truthiness of the
+    sparsity value exactly as there (rnn.py:855-860)."""
+    mats = mod.getVars()
+    endW = mod._num_W_matrices
+    endU = endW + mod._num_U_matrices
+    total = 2
+    for i in range(0, endW):
+        total += utils.countNNZ(mats[i], mod._wSparsity)
+    for i in range(endW, endU):
+        total += utils.countNNZ(mats[i], mod._uSparsity)
+    for i in range(endU, len(mats)):
+        total += utils.countNNZ(mats[i], False)
+    return total * 4
+
+
+def _copy_previous_UW(mod):
+    mats = mod.getVars()
+    n = mod._num_W_matrices + mod._num_U_matrices
+    mod.oldmats = [mats[i].detach().clone() for i in range(n)]
+
+
+def _sparsify(mod):
+    """Hard-threshold W/U (or their factors) IN PLACE and remember the support.  This is what the CPU cell does
+    (``mats[i].data = utils.hardThreshold(...)``, rnn.py:433-443); the reference's CUDA class rebinds list
+    entries instead (rnn.py:875-883), which leaves its parameters untouched -- a defect not reproduced."""
+    mats = mod.getVars()
+    endW = mod._num_W_matrices
+    endU = endW + mod._num_U_matrices
+    for i in range(0, endW):
+        utils.hardThreshold(mats[i], mod._wSparsity)
+    for i in range(endW, endU):
+        utils.hardThreshold(mats[i], mod._uSparsity)
+    _copy_previous_UW(mod)
+
+
+def _sparsify_with_support(mod):
+    mats = mod.getVars()
+    endU = mod._num_W_matrices + mod._num_U_matrices
+    for i in range(0, endU):
+        utils.supportBasedThreshold(mats[i], mod.oldmats[i])
+
+
 class FastGRNNCUDACell(nn.Module):
     """Single-step GPU cell (rnn.py:454-549).
 
@@ -209,6 +254,7 @@ class FastGRNNCUDACell(nn.Module):
         self._num_weight_matrices = [self._num_W_matrices, self._num_U_matrices, self._num_biases]
         _make_params(self, input_size, hidden_size, wRank, uRank, zetaInit, nuInit, self.device)
         self._gate_non_linearity = NON_LINEARITY[gate_nonlinearity]   # KeyError on others, as rnn.py:512
+        self.oldmats = []
 
     @property
     def name(self):
@@ -237,6 +283,18 @@ class FastGRNNCUDACell(nn.Module):
 
     def getVars(self):
         return _get_vars(self)
+
+    def get_model_size(self):
+        return _get_model_size(self)
+
+    def copy_previous_UW(self):
+        _copy_previous_UW(self)
+
+    def sparsify(self):
+        _sparsify(self)
+
+    def sparsifyWithSupport(self):
+        _sparsify_with_support(self)
 
 
 class FastGRNNCUDA(nn.Module):
@@ -306,3 +364,19 @@ class FastGRNNCUDA(nn.Module):
 
     def getVars(self):
         return _get_vars(self)
+
+    def get_model_size(self):
+        """rnn.py:843-865."""
+        return _get_model_size(self)
+
+    def copy_previous_UW(self):
+        """rnn.py:867-873."""
+        _copy_previous_UW(self)
+
+    def sparsify(self):
+        """rnn.py:875-883 (with the in-place effect the CPU cell has, rnn.py:433-443)."""
+        _sparsify(self)
+
+    def sparsifyWithSupport(self):
+        """rnn.py:885-889."""
+        _sparsify_with_support(self)

@@ -133,3 +133,54 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("test oracle", ""), os.path.join(dirpath, f)
+
+
+# ---- sparsification helpers: device-side mirrors of the reference's utils.py:53-114 ---------
+def _np_hard_threshold(a, s):
+    """The reference's arithmetic restated with numpy (utils.py:57-63)."""
+    import numpy as np
+    a = a.copy().ravel()
+    if len(a):
+        th = np.percentile(np.abs(a), (1 - s) * 100.0, method="higher")
+        a[np.abs(a) < th] = 0.0
+    return a
+
+
+def test_hard_threshold_matches_numpy_percentile_higher():
+    import numpy as np
+    import torch
+    from kws_amd import utils as U
+    rng = np.random.default_rng(0)
+    for shape in ((128, 128), (128, 32), (7, 3), (1, 1), (0,)):
+        for s in (1.0, 0.5, 0.31, 0.1, 0.013, 0.0):
+            a = rng.standard_normal(shape).astype(np.float32)
+            if a.size > 4:
+                a.ravel()[:3] = a.ravel()[3]              # ties
+            t = torch.from_numpy(a.copy())
+            out = U.hardThreshold(t, s)
+            assert out is t
+            np.testing.assert_array_equal(t.numpy().ravel(), _np_hard_threshold(a, s), err_msg="%s s=%g" % (shape, s))
+
+
+def test_support_threshold_model_size_and_module_methods():
+    import torch
+    from kws_amd import utils as U
+    from kws_amd.rnn import FastGRNNCUDA
+    src = torch.tensor([[0.0, 1.0], [2.0, 0.0]])
+    dst = torch.tensor([[5.0, 6.0], [7.0, 8.0]])
+    assert torch.equal(U.supportBasedThreshold(dst, src), torch.tensor([[0.0, 6.0], [7.0, 0.0]]))
+    assert U.estimateNNZ(torch.zeros(10, 10), 0.3) == (30, 240, True) and U.estimateNNZ(torch.zeros(10, 10), 0.5) == (100, 400, False)
+    assert U.countNNZ(src, True) == 2 and U.countNNZ(src, False) == 4
+    m = FastGRNNCUDA(32, 128, wSparsity=0.25, uSparsity=0.1, device="cpu")
+    # zeta and nu are counted twice, as in the reference ("totalnnz = 2" plus their getVars entries, rnn.py:851,861)
+    dense_bytes = 4 * (128 * 32 + 128 * 128 + 2 * 128 + 2 + 2)
+    assert m.get_model_size() == dense_bytes                 # nothing is zero yet: non-zero counts = sizes
+    m.sparsify()
+    nzW, nzU = int((m.W != 0).sum()), int((m.U != 0).sum())
+    assert abs(nzW - 0.25 * 128 * 32) <= 2 and abs(nzU - 0.1 * 128 * 128) <= 2
+    assert m.get_model_size() == 4 * (nzW + nzU + 2 * 128 + 2 + 2)
+    with torch.no_grad():
+        m.W.add_(1.0); m.U.add_(1.0)                         # a training step fills the zeros again ...
+    m.sparsifyWithSupport()                                  # ... and the remembered support removes them
+    assert int((m.W != 0).sum()) <= nzW and int((m.U != 0).sum()) <= nzU
+    assert torch.equal(m.W == 0, m.oldmats[0] == 0)
