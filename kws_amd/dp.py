@@ -62,21 +62,48 @@ class GradBucket:
         if not missing:                       # the usual case: ONE fused copy kernel, like pack_()
             torch._foreach_copy_([p.grad.view(-1) for p in self.params], self.views)
 
-    def all_reduce_(self):
-        """pack (1 kernel) -> one collective -> unpack (1 kernel).  With the RCCL backend and the default
-        divisor the mean is taken inside the collective (ReduceOp.AVG), otherwise SUM + one scale."""
-        self.pack_()
+    def shared_flat_(self):
+        """If every ``p.grad`` is a view of one storage, laid out back to back in parameter order -- which
+        is how ``kws_amd.fastgrnn_cuda`` allocates the operator's gradient outputs and how autograd then
+        adopts them -- return a flat tensor ALIASING them (no copy); else None."""
+        grads = [p.grad for p in self.params]
+        if any(g is None or not g.is_contiguous() for g in grads):
+            return None
+        g0 = grads[0]
+        base = g0.untyped_storage().data_ptr()
+        off = g0.storage_offset()
+        for g, n in zip(grads, self.sizes):
+            if g.dtype != g0.dtype or g.device != g0.device or g.untyped_storage().data_ptr() != base \
+                    or g.storage_offset() != off:
+                return None
+            off += n
+        return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), g0.storage_offset(),
+                                                                      (self.total,))
+
+    def _collective_(self, t):
         avg_in_collective = (self._avg_ok and self.divisor == float(self.world) and self.world > 1
                              and dist.get_backend(self.group) == "nccl")
         if avg_in_collective:
             try:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
             except RuntimeError:              # a backend build without ncclAvg: fall back for good
                 self._avg_ok = avg_in_collective = False
         if not avg_in_collective:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             if self.divisor != 1.0:
-                self.flat.mul_(1.0 / self.divisor)
+                t.mul_(1.0 / self.divisor)
+
+    def all_reduce_(self):
+        """One collective over all parameter gradients.  Zero-copy when the gradients already share one flat
+        buffer (see shared_flat_); otherwise pack (1 kernel) -> collective -> unpack (1 kernel).  With the
+        RCCL backend and the default divisor the mean is taken inside the collective (ReduceOp.AVG),
+        otherwise SUM + one scale."""
+        shared = self.shared_flat_()
+        if shared is not None:
+            self._collective_(shared)
+            return shared
+        self.pack_()
+        self._collective_(self.flat)
         self.unpack_()
         return self.flat
 

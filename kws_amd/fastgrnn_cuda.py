@@ -242,15 +242,24 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         mk = lambda *s: torch.empty(s, dtype=pdt, device=dev)
         none = lambda: torch.empty(0)
         d_input = torch.empty(tuple(input.shape), dtype=dt, device=dev)
-        d_bz, d_bh = mk(1, H), mk(1, H)
-        d_zeta, d_nu = mk(1, 1), mk(1, 1)
         d_old_h = mk(B, H)
-        d_w = none() if w_lr else mk(H, F)
-        d_u = none() if u_lr else mk(H, H)
-        d_w1 = mk(*w1.shape) if w_lr else none()
-        d_w2 = mk(*w2.shape) if w_lr else none()
-        d_u1 = mk(*u1.shape) if u_lr else none()
-        d_u2 = mk(*u2.shape) if u_lr else none()
+        # The parameter gradients are views of ONE flat buffer, laid out in the order the modules register
+        # their parameters (W | W1,W2 ; U | U1,U2 ; bias_gate ; bias_update ; zeta ; nu).  autograd adopts
+        # them as the .grad tensors, so a data-parallel step can all-reduce that buffer in place
+        # (kws_amd.dp.GradBucket) instead of packing and unpacking six tensors.
+        shapes = ([tuple(w1.shape), tuple(w2.shape)] if w_lr else [(H, F)]) + \
+                 ([tuple(u1.shape), tuple(u2.shape)] if u_lr else [(H, H)]) + [(1, H), (1, H), (1, 1), (1, 1)]
+        sizes = [a * b for a, b in shapes]
+        flat = torch.empty(sum(sizes), dtype=pdt, device=dev)
+        views = [v.view(sh) for v, sh in zip(flat.split(sizes), shapes)]
+        nw = 2 if w_lr else 1
+        nu_ = 2 if u_lr else 1
+        d_w = none() if w_lr else views[0]
+        d_w1, d_w2 = (views[0], views[1]) if w_lr else (none(), none())
+        d_u = none() if u_lr else views[nw]
+        d_u1, d_u2 = (views[nw], views[nw + 1]) if u_lr else (none(), none())
+        d_bz, d_bh, d_zeta, d_nu = views[nw + nu_:nw + nu_ + 4]
+        del flat, views
         grads = _lib.Grads(_ptr(d_input), _ptr(d_bz), _ptr(d_bh), _ptr(d_zeta), _ptr(d_nu), _ptr(d_old_h),
                            _ptr(d_w), _ptr(d_u), _ptr(d_w1), _ptr(d_w2), _ptr(d_u1), _ptr(d_u2))
         nbytes = lib.fastgrnn_hip_backward_workspace_bytes(C.byref(desc))

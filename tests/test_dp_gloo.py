@@ -120,3 +120,23 @@ def test_bucket_size_northstar():
     assert GradBucket(list(m.parameters()), world=8).total * 4 == 82952
     m = FastGRNNCUDA(32, 256, wRank=16, uRank=16, device="cpu")
     assert GradBucket(list(m.parameters()), world=8).total * 4 == 53256
+
+
+def test_grad_bucket_detects_gradients_that_share_one_buffer():
+    """Zero-copy path of GradBucket: gradients that are back-to-back views of one storage (how the operator
+    shim allocates them) are all-reduced in place; anything else falls back to pack/unpack."""
+    sys.path.insert(0, ROOT)
+    from kws_amd.dp import GradBucket
+    params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(1, 5)), torch.nn.Parameter(torch.zeros(1, 1))]
+    flat = torch.arange(18, dtype=torch.float32)
+    for p_, v in zip(params, flat.split([12, 5, 1])):
+        p_.grad = v.view_as(p_)
+    bucket = GradBucket(params, world=1, divisor=1)
+    shared = bucket.shared_flat_()
+    assert shared is not None and shared.data_ptr() == flat.data_ptr() and torch.equal(shared, flat)
+    shared.mul_(2.0)                                            # what an in-place collective does
+    assert torch.equal(params[1].grad, 2.0 * torch.arange(12, 17, dtype=torch.float32).view(1, 5))
+    params[1].grad = params[1].grad.clone()                     # one gradient elsewhere: no aliasing possible
+    assert bucket.shared_flat_() is None
+    params[1].grad = None
+    assert bucket.shared_flat_() is None

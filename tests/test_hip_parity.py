@@ -630,6 +630,9 @@ def test_grad_bucket_on_rccl_single_rank():
         before = [p_.grad.clone() for p_ in m.parameters()]
         bucket = GradBucket(list(m.parameters()))
         assert bucket.total == 128 * 32 + 128 * 128 + 2 * 128 + 2          # 20 738 floats
+        # the operator's gradient outputs are views of one flat buffer and autograd adopts them as .grad:
+        # the bucket all-reduces that buffer in place (no pack / unpack kernels)
+        assert bucket.shared_flat_() is not None
         bucket.all_reduce_()
         torch.cuda.synchronize()
         for a, p_ in zip(before, m.parameters()):
