@@ -127,13 +127,13 @@ def main():
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16 sequences (x, hs, grad_hs, d_x); fp32 state, parameters, gradients (3xbf16 split MFMA, fp32 accumulate)"
+            "dtype": ("bf16 sequences (x, hs, grad_hs, d_x); fp32 state, parameters, gradients (split-precision MFMA, fp32 accumulate)"
                       if args.io == "bf16" else
-                      "f32 (3xbf16 split MFMA, fp32 accumulate)" if split else "f32"),
+                      "f32 (split-precision MFMA: exact 3xbf16 planes, fp16 two-plane forward state product; fp32 accumulate)" if split else "f32"),
             "data": "synthetic",
             "config": {"workload": "FastGRNN dense fwd+bwd training step (FastGRNNCUDA module + autograd), T=99 F=32 "
                                    "H=128 B=%d per GPU, fp32 results, dense grad_hs; %s" % (
-                                       B, "3xbf16 split-precision MFMA kernels, one saved [T,B,H] tensor" if split
+                                       B, "split-precision MFMA kernels, one saved [T,B,H] tensor" if split
                                        else "z_s/h_prime_s saved as the reference operator does"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernel_path": {"forward": path_f, "backward": path_b}},
