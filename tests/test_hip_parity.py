@@ -747,3 +747,34 @@ def test_module_takes_the_trainers_permuted_view():
     assert torch.equal(hs1, hs2) and torch.equal(a1.grad, a2.grad)
     for n, p_ in m.named_parameters():
         assert torch.equal(g1[n], p_.grad), n
+
+
+@pytest.mark.parametrize("B", [48, 37])
+def test_ab_kernel_variants_agree_with_the_default(B):
+    """The A/B flags select older kernel shapes / operand formats of the same arithmetic: 4-wave forward (8),
+    three-bf16-plane forward state product (64), 4-wave backward (32).  They must agree with the default
+    kernels to fp32 rounding (they differ in summation order and, for 64, in the operand split)."""
+    T, F, H = 40, 32, 128
+    SAVE_PREACT, FWD_4WAVE, BWD_4WAVE, FWD_BF16X3 = 4, 8, 32, 64
+    p = O.make_params(F, H, seed=12, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+
+    def run(flags):
+        outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"],
+                                            h0, 0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+        gr = fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1], h0,
+                                           P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags, **kw)
+        return list(outs) + list(gr[:8])
+
+    ref = run(SAVE_PREACT)
+    for extra in (FWD_4WAVE, FWD_BF16X3, FWD_4WAVE | FWD_BF16X3, BWD_4WAVE, FWD_4WAVE | BWD_4WAVE):
+        got = run(SAVE_PREACT | extra)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            scale = max(1.0, float(a.abs().max()))
+            tol = 2e-3 if k in (5, 6) else 2e-5           # d_zeta, d_nu: ill-conditioned scalar sums
+            assert float((a - b).abs().max()) / scale <= tol, (extra, k)
