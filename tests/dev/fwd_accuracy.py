@@ -2,7 +2,7 @@
 flags 4 = default (fp16 two-plane state product), 4|64 = three bf16 planes, 4|8 = 4-wave kernel; also the
 generic fp32 scan (flag 1) as the plain-fp32 yardstick.  Weight scales 0.1 (reference init), 0.01, 1.0."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from kws_amd import fastgrnn_cuda
 from oracle import fastgrnn_oracle as O
