@@ -1373,8 +1373,10 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       if (acc[0][C0 + NB - 1][0] + acc[1][C0 + NB - 1][0] == 1.2345678e38f) S.red[15] = 1.f;
       __builtin_amdgcn_sched_barrier(0);
     };
-    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-    batch(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+    // batches of 2 + 2 + 1 column tiles: with 3 + 2 the kernel spilled nine registers inside the loop
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    batch(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
   };
 
   const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
