@@ -97,7 +97,7 @@ typedef enum fastgrnn_nonlinearity {
 /* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
  * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
 #define FASTGRNN_FLAG_FWD_BF16X3 64u
-/* A/B only: run the dense split-precision backward as the older 4-wave kernel instead of the 8-wave one. */
+/* Retired: selected an older 4-wave backward kernel; accepted and ignored (the 8-wave backward always runs). */
 #define FASTGRNN_FLAG_BWD_4WAVE 32u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */

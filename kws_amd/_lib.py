@@ -21,7 +21,7 @@ FLAG_FORCE_F32_MFMA = 2
 FLAG_SAVE_PREACT = 4
 FLAG_FWD_4WAVE = 8            # A/B: older 4-wave forward shape
 FLAG_FWD_BF16X3 = 64          # A/B: forward state product on three bf16 planes
-FLAG_BWD_4WAVE = 32           # A/B: older 4-wave backward shape
+FLAG_BWD_4WAVE = 32           # retired (accepted and ignored): the 4-wave backward is gone
 FLAG_X_BFT = 128              # x / d_x are the trainer's [B,F,T]
 FLAG_BATCH_MAJOR = 16         # sequences are [B,T,.] (batch_first) instead of [T,B,.]
 

@@ -116,24 +116,45 @@ __device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(f
 // {hi16(b), hi16(a)} -> one dword of two bf16 (element order a, b)
 __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// ---- the exact three-plane split -----------------------------------------------------------------------
+// v = p0 + p1 + p2 with p0 = bf16(v), p1 = bf16(v - p0), p2 = v - p0 - p1 (<= 8 significant bits left: exact),
+// every conversion ROUND-TO-NEAREST-EVEN on the hardware converter (v_cvt_pk_bf16_f32, two values per
+// instruction).  Rounding, not truncating, matters: truncated planes all carry the sign of v, so the three
+// dropped cross terms (p1.q2 + p2.q1 + p2.q2) pushed every product toward zero by ~4e-8 relative -- harmless
+// per product, but one-signed, and it showed in the two scalar gradients that sum a million terms (d_zeta,
+// d_nu: 3e-4 relative against 1e-5 for the fp32 paths; tests/dev/bias_probe.py).  With rounded planes the
+// dropped terms are zero-mean and below 2^-26.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {            // {bf16(b), bf16(a)}: element order a, b
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// two values -> one dword (two bf16) per plane
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& q0, unsigned& q1, unsigned& q2) {
+  q0 = pk_bf16(a, b);
+  const float ra = a - bitsf(q0 << 16), rb = b - bitsf(q0 & 0xFFFF0000u);
+  q1 = pk_bf16(ra, rb);
+  q2 = pk_bf16(ra - bitsf(q1 << 16), rb - bitsf(q1 & 0xFFFF0000u));
+}
+// four values -> 8 bytes (four bf16) per plane
+__device__ __forceinline__ void split_quad(const f32x4 v, uint2& p0, uint2& p1, uint2& p2) {
+  split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+  split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+}
+// one value -> one bf16 per plane
+__device__ __forceinline__ void split_one(float v, unsigned short& s0, unsigned short& s1, unsigned short& s2) {
+  unsigned q0, q1, q2;
+  split_pair(v, 0.0f, q0, q1, q2);
+  s0 = (unsigned short)q0; s1 = (unsigned short)q1; s2 = (unsigned short)q2;
+}
 __device__ __forceinline__ Frag3 split3(const f32x4 lo, const f32x4 hi) {
-  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  unsigned b0[8], b1[8], b2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    b0[j] = fbits(v[j]);
-    const float r1 = v[j] - bitsf(b0[j] & 0xFFFF0000u);
-    b1[j] = fbits(r1);
-    const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
-    b2[j] = fbits(r2);                       // <= 8 significant bits left: its low half is zero
-  }
+  uint2 a0, a1, a2, b0, b1, b2;
+  split_quad(lo, a0, a1, a2);
+  split_quad(hi, b0, b1, b2);
   Frag3 f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f.p[0][q] = pack_hi(b0[2 * q], b0[2 * q + 1]);
-    f.p[1][q] = pack_hi(b1[2 * q], b1[2 * q + 1]);
-    f.p[2][q] = pack_hi(b2[2 * q], b2[2 * q + 1]);
-  }
+  f.p[0] = u32x4{a0.x, a0.y, b0.x, b0.y};
+  f.p[1] = u32x4{a1.x, a1.y, b1.x, b1.y};
+  f.p[2] = u32x4{a2.x, a2.y, b2.x, b2.y};
   return f;
 }
 
@@ -167,6 +188,12 @@ __device__ __forceinline__ f32x4 mfma3h(const Frag2h& a, const Frag2h& b, f32x4 
   return acc;
 }
 
+__device__ __forceinline__ void mfma3h_hl(const Frag2h& a, const Frag2h& b, f32x4& hi, f32x4& lo) {   // see mfma6_hl
+  lo = mfma_f16(a.lo, b.hi, lo);
+  lo = mfma_f16(a.hi, b.lo, lo);
+  hi = mfma_f16(a.hi, b.hi, hi);
+}
+
 // acc += sum over the six retained plane pairs of A[pa] . B[pb]   (small terms first)
 __device__ __forceinline__ f32x4 mfma6(const Frag3& a, const Frag3& b, f32x4 acc) {
   acc = mfma_bf16(a.p[2], b.p[0], acc);
@@ -178,11 +205,30 @@ __device__ __forceinline__ f32x4 mfma6(const Frag3& a, const Frag3& b, f32x4 acc
   return acc;
 }
 
+// The same six terms with the five small ones in an accumulator of their own (lo, started at zero by the caller
+// and added to hi at the end): inside one MFMA every product is aligned to the largest addend -- including C --
+// and chopped there, so small-term products added straight into a large running sum lose their low bits
+// (tools/mfma_round_probe.hip).
+__device__ __forceinline__ void mfma6_hl(const Frag3& a, const Frag3& b, f32x4& hi, f32x4& lo) {
+  lo = mfma_bf16(a.p[2], b.p[0], lo);
+  lo = mfma_bf16(a.p[1], b.p[1], lo);
+  lo = mfma_bf16(a.p[0], b.p[2], lo);
+  lo = mfma_bf16(a.p[1], b.p[0], lo);
+  lo = mfma_bf16(a.p[0], b.p[1], lo);
+  hi = mfma_bf16(a.p[0], b.p[0], hi);
+}
+
+// Keeps a fragment's registers allocated up to this point, ordered after whatever produced `tie` (pass a value
+// read from the youngest accumulator: once that has been read the matrix pipe has drained).  No instruction.
+__device__ __forceinline__ void keep_alive(float& tie, const Frag3& f) {
+  asm volatile("" : "+v"(tie) : "v"(f.p[0]), "v"(f.p[1]), "v"(f.p[2]));
+}
+
 // ------------------------------------------------------------------------------------------
 // forward  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
 // AUX: 0 = hs only; 1 = also z_s, h_prime_s (the reference operator's outputs); 2 = also the
-// pre-activation W.x+U.h into zs (FASTGRNN_FLAG_SAVE_PREACT, consumed by bwd_scan_split<PREACT>).
+// pre-activation W.x+U.h into zs (FASTGRNN_FLAG_SAVE_PREACT, consumed by bwd_scan_split_w8<PREACT>).
 template <int GATE, int AUX, bool RAGGED>
 __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
     int Tn, int B, int rsT, int rsB, const float* __restrict__ x, const float* __restrict__ h0,
@@ -266,11 +312,13 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int p = 0; p < 3; ++p) hB[s].p[p] = hl[cur][p][(s * 4 + g) * 16 + i];
+    __builtin_amdgcn_sched_barrier(0);       // every state-plane read is issued before the first MFMA (operand rule)
     // The two row tiles run one after the other: tile 0's VALU epilogue then sits under tile 1's MFMA
     // chain (the bf16 matrix pipe overlaps with the VALU).  W.x_t goes first in each tile: it does not
     // depend on h, so it (and the x split) covers the LDS round trip of the state planes.
     const Frag3 xB = split3(xuse.lo, xuse.hi);
     auto tile_chain = [&](int mt) __attribute__((always_inline)) {
+      // (one accumulator: this A/B kernel keeps the plain six-term chain; mfma6_hl is in the 8-wave kernels)
       f32x4 a = mfma6(Wf[mt], xB, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int s = 0; s < KS; ++s) a = mfma6(Uf[mt][s], hB[s], a);                        // .cu:368
@@ -312,6 +360,16 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(2)
     // ---- tile 1 epilogue, planes of h_t
+    {
+      // the operand registers stay allocated until the youngest accumulator has been read (= the chains have
+      // retired): nothing may be loaded into a fragment behind an MFMA that still has to fetch it
+      float probe = acc1[0];
+      keep_alive(probe, xB);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) keep_alive(probe, hB[s]);
+      if (probe == 1.2345678e38f) hown[0][0] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     tile_epilogue(1, acc1);
     const Frag3 f = split3(hown[0], hown[1]);
 #pragma unroll
@@ -337,6 +395,15 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
     store_step(Tn - 1, gb);
   } else {
     store_step(Tn - 1, ga);
+  }
+  {                                           // ... and the weight fragments through the last step
+    float probe = hown[0][0];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      keep_alive(probe, Wf[mt]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) keep_alive(probe, Uf[mt][s]);
+    }
   }
 #ifdef FASTGRNN_DIAG_STAMPS
   if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
@@ -428,29 +495,19 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
       *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = lo;
       return;
     }
-    unsigned b0[4], b1[4], b2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b0[j] = fbits(hown[j]);
-      const float r1 = hown[j] - bitsf(b0[j] & 0xFFFF0000u);
-      b1[j] = fbits(r1);
-      const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
-      b2[j] = fbits(r2);
-    }
-    *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
-    *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
-    *reinterpret_cast<uint2*>(&hpl[buf][2][off]) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
+    uint2 q0, q1, q2;
+    split_quad(hown, q0, q1, q2);
+    *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = q0;
+    *reinterpret_cast<uint2*>(&hpl[buf][1][off]) = q1;
+    *reinterpret_cast<uint2*>(&hpl[buf][2][off]) = q2;
   };
   auto publish_x = [&](int buf, float v) __attribute__((always_inline)) {
-    const unsigned a0 = fbits(v);
-    const float r1 = v - bitsf(a0 & 0xFFFF0000u);
-    const unsigned a1 = fbits(r1);
-    const float r2 = r1 - bitsf(a1 & 0xFFFF0000u);
-    const unsigned a2 = fbits(r2);
+    unsigned short s0, s1, s2;
+    split_one(v, s0, s1, s2);
     const unsigned off = xu * W8_ROWX + xf * 2;
-    *reinterpret_cast<unsigned short*>(&xpl[buf][0][off]) = (unsigned short)(a0 >> 16);
-    *reinterpret_cast<unsigned short*>(&xpl[buf][1][off]) = (unsigned short)(a1 >> 16);
-    *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = (unsigned short)(a2 >> 16);
+    *reinterpret_cast<unsigned short*>(&xpl[buf][0][off]) = s0;
+    *reinterpret_cast<unsigned short*>(&xpl[buf][1][off]) = s1;
+    *reinterpret_cast<unsigned short*>(&xpl[buf][2][off]) = s2;
   };
   // x is [T,B,F] / [B,T,F] (rsT, rsB) or, with FASTGRNN_FLAG_X_BFT, the trainer's [B,F,T]: this lane's value of
   // frame t is x[xbase + t * xstep]
@@ -505,15 +562,18 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     // them through fewer registers); the waits for them stay progressive
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
-    f32x4 a = mfma6(Wf, xB, f32x4{0.f, 0.f, 0.f, 0.f});
+    // big and small terms in accumulators of their own (see mfma6_hl), summed once at the end
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, alo = a;
+    mfma6_hl(Wf, xB, a, alo);
     if (F16H) {
-      f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f}, ahlo = ah;
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) ah = mfma3h(Uh[s2], hH[s2], ah);                   // .cu:368, scaled by 2^k
-      a += ah * u_unscale;
+      for (int s2 = 0; s2 < KS; ++s2) mfma3h_hl(Uh[s2], hH[s2], ah, ahlo);               // .cu:368, scaled by 2^k
+      a = (a + alo) + (ah + ahlo) * u_unscale;
     } else {
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) a = mfma6(Uf[s2], hB[s2], a);                      // .cu:368
+      for (int s2 = 0; s2 < KS; ++s2) mfma6_hl(Uf[s2], hB[s2], a, alo);                  // .cu:368
+      a += alo;
     }
     f32x4 zq, cq;
     SPLIT_STAMP(2)
@@ -629,7 +689,6 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
   auto step = [&](auto first_tag, int t, int cur, Feat& xuse, Feat& xload, Gates& gprev,
                   Gates& gout) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    load_x(t + 1 < Tn ? t + 1 : t, xload);
     // ---- A: rank-space partials ------------------------------------------------------------
     const Frag3 xB = split3(xuse.lo, xuse.hi);
     f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -641,6 +700,10 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
     lds_barrier();
+    // The request for x_{t+1} goes out here: every MFMA issued so far has retired (its result went through LDS
+    // above), so the load cannot land in an operand register that the matrix pipe still has to fetch.
+    load_x(t + 1 < Tn ? t + 1 : t, xload);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- m = sum of the partials; this lane's B fragment is rows 8g..8g+7 of [m_h ; m_x] -------
     f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
 #pragma unroll
@@ -681,6 +744,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
   Feat xa, xb;
   Gates ga, gb;
   load_x(0, xa);
+  __builtin_amdgcn_sched_barrier(0);         // every prologue request is out before the first MFMA
   step(std::true_type{}, 0, 0, xa, xb, gb, ga);
   int t = 1;
   for (; t + 1 < Tn; t += 2) {
@@ -720,17 +784,6 @@ constexpr int PLANE_H = 16 * ROW_H;    // 4608
 constexpr int PLANE_X = 16 * ROW_X;    // 1536
 constexpr int IMG = 2 * 3 * PLANE_H + 3 * PLANE_X;   // one step's images: d_pre | h_prev | x  (32256 B)
 
-struct BwdSplitLds {
-  // Per step s, buffer s&3: natural [utterance][unit] images of the exact bf16 planes of d_pre_s,
-  // h_{s-1} and x_s.  Each is read two ways: as MFMA B fragments (ds_read_b128: 8 consecutive units
-  // of one utterance, the chain) and transposed (ds_read_b64_tr_b16: 8 consecutive utterances of
-  // one unit) for the K = utterance products dW, dU.  The MFMA's K is 32 and a tile has 16
-  // utterances, so dW/dU contract TWO consecutive steps per MFMA (lane groups 0,1 = step s+1,
-  // groups 2,3 = step s); four buffers keep a pair readable for the two iterations that share it.
-  unsigned char img[4][IMG];
-  f32x4 DX[2][4][2][64];               // d_x partial sums of every wave, per feature tile
-  float red[8];
-};
 constexpr int OFF_DP = 0, OFF_HP = 3 * PLANE_H, OFF_XP = 6 * PLANE_H;
 
 // One transposed fragment (8 bf16: utterances +0..7 of this lane's 8-row block, one unit column) =
@@ -747,383 +800,16 @@ __device__ __forceinline__ u32x4 tr_frag(unsigned lds_byte_addr, int rowb) {
   return __builtin_bit_cast(u32x4, v);
 }
 
-// Reverse scan, pipelined like bwd_scan_mfma (kernels_mfma.hip).  Iteration t:
-//   top    B fragments of d_pre_t (LDS); 12 register-only d_x(t+1) MFMAs cover the round trip
-//   chain  d_h = z*g + U^T d_pre_t: 48 MFMAs (2 dependent chains); global requests in their shadow
-//   5 x    { 12 independent dW/dU MFMAs of one column tile of a step PAIR  ||  a slice of EW(t-1) }
-//   end    planes of d_pre_{t-1}, h_{t-2}, x_{t-1} published; one raw barrier
-// Even t does column tiles 0..4 of pair (t+1, t), odd t tiles 5..9 of pair (t+2, t+1).
-// PREACT: aux0 holds the pre-activation W x + U h saved by the forward (one tensor) and z, c are
-// recomputed here; otherwise aux0 = z_s, aux1 = h_prime_s (the reference operator's tensors).
-template <int GATE, bool PREACT, bool RAGGED>
-__global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void bwd_scan_split(
-    int Tn, int B, int rsT, int rsB, const float* __restrict__ ghs, const float* __restrict__ x,
-    const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
-    const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
-    const float* __restrict__ bz, const float* __restrict__ bh,
-    const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ d_x, float* __restrict__ d_h0, float* __restrict__ part) {
-  constexpr int H = 128, F = 32, MT = 2, KS = 4, NCT = 8, NFT = 2;
-  __shared__ BwdSplitLds S;
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63, i = l & 15, g = l >> 4;
-  const int b = blockIdx.x * 16 + i;
-  const bool valid = !RAGGED || b < B;
-  const int bc = valid ? b : B - 1;
-  const int n0 = wv * 32 + g * 8;                    // this lane's 8 hidden units
-  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
-  // Odd T: step T-1 has no partner; it is paired with a virtual step T whose images are zero.
-  if (Tn & 1) {
-    for (int idx = tid; idx < IMG / 4; idx += 256) reinterpret_cast<unsigned*>(&S.img[Tn & 3][0])[idx] = 0u;
-  }
-
-  // ---- resident A operands ------------------------------------------------------------------
-  // chain: d_h[k][b] = sum_n U[n][k] d_pre[b][n]; A row i of tile mt is k = 32wv + 8(i>>2) + 4mt + (i&3)
-  Frag3 UTf[MT][KS];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int kA = wv * 32 + (i >> 2) * 8 + mt * 4 + (i & 3);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      f32x4 lo, hi;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = u[(size_t)(32 * s + 8 * g + j) * H + kA];
-        hi[j] = u[(size_t)(32 * s + 8 * g + 4 + j) * H + kA];
-      }
-      UTf[mt][s] = split3(lo, hi);
-    }
-  }
-  // d_x[f][b] = sum_n W[n][f] d_pre[b][n] over this wave's own units: the K-step is the lane's own fragment
-  Frag3 WTf[NFT];
-#pragma unroll
-  for (int f2 = 0; f2 < NFT; ++f2) {
-    f32x4 lo, hi;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      lo[j] = w[(size_t)(n0 + j) * F + f2 * 16 + i];
-      hi[j] = w[(size_t)(n0 + 4 + j) * F + f2 * 16 + i];
-    }
-    WTf[f2] = split3(lo, hi);
-  }
-  f32x4 bzv[MT], bhv[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    bzv[mt] = PREACT ? ld4(bz + n0 + 4 * mt) : f32x4{0.f, 0.f, 0.f, 0.f};
-    bhv[mt] = PREACT ? ld4(bh + n0 + 4 * mt) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  f32x4 accU[MT][NCT], accW[MT][NFT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a) {
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) accU[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NFT; ++c) accW[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  f32x4 sbz[MT], sbh[MT], dh[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
-  float pz = 0.f, pn = 0.f;
-
-  // lane-constant LDS byte offsets (within one step's image block)
-  const unsigned lds_img = (unsigned)(size_t)&S.img[0][0];
-  const unsigned my_row_h = (unsigned)(i * ROW_H + n0 * 2);          // producer slot == B-fragment slot of (b=i, own units)
-  const int xb = wv * 4 + ((l >> 2) & 3), xf0 = (l & 3) * 8;         // x plane producer: row xb, features xf0..+7
-  const unsigned my_row_x = (unsigned)(xb * ROW_X + xf0 * 2);
-  const int q = (l & 15) >> 2, pp = l & 3;
-  // transposed-read offsets: utterance block 8(g&1) of the step that this lane group covers
-  const unsigned trA_off = OFF_DP + (8 * (g & 1) + q) * ROW_H + (wv * 32 + 4 * pp) * 2;   // d_pre^T rows 32wv + 16a + i
-  const unsigned trH_off = OFF_HP + (8 * (g & 1) + q) * ROW_H + (4 * pp) * 2;             // h_prev^T column 16c + i
-  const unsigned trX_off = OFF_XP + (8 * (g & 1) + q) * ROW_X + (4 * pp) * 2;             // x^T column 16f + i
-
-  struct EwOps { f32x4 g[MT], a0[MT], a1[MT], h[MT]; };   // grad_hs, aux0 (z or pre), aux1 (c), h_prev
-  struct XRaw { f32x4 lo, hi; };
-  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
-    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      e.g[mt] = ld4(ghs + o + 4 * mt);
-      e.a0[mt] = ld4(aux0 + o + 4 * mt);
-      if (!PREACT) e.a1[mt] = ld4(aux1 + o + 4 * mt);
-      e.h[mt] = ld4(hprev + 4 * mt);
-    }
-  };
-  auto load_xraw = [&](int t, XRaw& r) __attribute__((always_inline)) {
-    const int bb = blockIdx.x * 16 + xb;
-    const float* xp = x + ((size_t)t * rsT + (size_t)((!RAGGED || bb < B) ? bb : B - 1) * rsB) * F + xf0;
-    r.lo = ld4(xp); r.hi = ld4(xp + 4);
-  };
-
-  // EW(t): .cu:107-117, split by dependence so that the VALU always has work beside the matrix pipe:
-  //   ew_pre   everything that does not need d_old_h: z, c (recomputed from the pre-activation when
-  //            PREACT) and the per-element factors of the derivative formulas; runs under chain(t+1)
-  //   ew_hx    planes of h_{t-1} and x_t into image buffer [t&3]; also under the chain
-  //   ew_post  gg = grad + d_old_h and the products with the factors (slices between the dW/dU tiles)
-  //   ew_publish_dp  planes of d_pre_t into the image buffer and into registers (for d_x)
-  // Leaves dh = z*g, the C-in of chain(t).
-  struct EwPre { f32x4 kc[MT], kz[MT], z[MT], tzc[MT], c[MT]; };
-  struct EwState { f32x4 dpv[MT]; };
-  auto ew_pre = [&](const EwOps& e, EwPre& f, f32x4 (&hpv)[MT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float z, c;
-        if (PREACT) {
-          z = gate_act<GATE>(e.a0[mt][r] + bzv[mt][r]);
-          c = ftanh(e.a0[mt][r] + bhv[mt][r]);
-        } else {
-          z = e.a0[mt][r]; c = e.a1[mt][r];
-        }
-        float hv = e.h[mt][r];
-        float kc = (sz * (1.0f - z) + sn) * (1.0f - c * c);       // d_pre_c = kc * gg   (.cu:109)
-        float kz = (hv - sz * c) * gate_dact<GATE>(z);            // d_pre_z = kz * gg   (.cu:110)
-        float tzc = (1.0f - z) * c;                               // d_zeta term          (.cu:114)
-        if (RAGGED && !valid) { kc = 0.f; kz = 0.f; z = 0.f; tzc = 0.f; c = 0.f; hv = 0.f; }
-        f.kc[mt][r] = kc; f.kz[mt][r] = kz; f.z[mt][r] = z; f.tzc[mt][r] = tzc; f.c[mt][r] = c;
-        hpv[mt][r] = hv;
-      }
-  };
-  auto ew_hx = [&](int t, const f32x4 (&hpv)[MT], const XRaw& xr) __attribute__((always_inline)) {
-    const Frag3 hf = split3(hpv[0], hpv[1]);
-    const Frag3 xf = split3(xr.lo, xr.hi);
-    unsigned char* im = &S.img[t & 3][0];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      *reinterpret_cast<u32x4*>(im + OFF_HP + p * PLANE_H + my_row_h) = hf.p[p];
-      *reinterpret_cast<u32x4*>(im + OFF_XP + p * PLANE_X + my_row_x) = xf.p[p];
-    }
-  };
-  auto ew_post = [&](int k, const EwOps& e, const EwPre& f, EwState& st) __attribute__((always_inline)) {   // element k = 0..7
-    const int mt = k >> 2, r = k & 3;
-    const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
-    const float dcp = f.kc[mt][r] * gg, dzp = f.kz[mt][r] * gg;
-    sbz[mt][r] += dzp; sbh[mt][r] += dcp;
-    pz += f.tzc[mt][r] * gg; pn += f.c[mt][r] * gg;                          // .cu:114-115
-    st.dpv[mt][r] = dzp + dcp;                                                // .cu:113
-    dh[mt][r] = f.z[mt][r] * gg;                                              // .cu:108
-  };
-  auto ew_publish_dp = [&](int t, const EwState& st, Frag3& dpo) __attribute__((always_inline)) {
-    dpo = split3(st.dpv[0], st.dpv[1]);
-    unsigned char* im = &S.img[t & 3][0];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(im + OFF_DP + p * PLANE_H + my_row_h) = dpo.p[p];
-  };
-  // d_x partial of step t over this wave's units (.cu:538): register operands only
-  auto dx_partial = [&](int t, const Frag3& dpo) __attribute__((always_inline)) {
-#pragma unroll
-    for (int f2 = 0; f2 < NFT; ++f2) S.DX[t & 1][wv][f2][l] = mfma6(WTf[f2], dpo, f32x4{0.f, 0.f, 0.f, 0.f});
-  };
-  auto finish_dx = [&](int t) __attribute__((always_inline)) {
-    if (wv < NFT) {                         // wave-uniform
-      f32x4 sacc = (S.DX[t & 1][0][wv][l] + S.DX[t & 1][1][wv][l]) + (S.DX[t & 1][2][wv][l] + S.DX[t & 1][3][wv][l]);
-      if (valid) st4(d_x + ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g, sacc);
-    }
-  };
-
-  // dW += d_pre_s^T x_s, dU += d_pre_s^T h_{s-1} (.cu:539-540) for the step pair (sU, sU-1): column tiles
-  // [5*HALF, 5*HALF+5) of the 10 (2 feature tiles of dW, 8 unit tiles of dU), 2 row tiles, 6 terms.
-  // Fragments come straight out of the plane images through the hardware transpose read, software-
-  // pipelined one column tile ahead; between(CT) is a slice of VALU work for the same region.
-  auto weight_grads = [&](auto half_tag, int sU, auto&& between) __attribute__((always_inline)) {
-    constexpr int HALF = decltype(half_tag)::value, C0 = 5 * HALF;
-    // lane groups 0,1 read step sU's images, groups 2,3 step sU-1's
-    const unsigned im = lds_img + (unsigned)(((g < 2) ? sU : sU - 1) & 3) * IMG;
-    const unsigned trA = im + trA_off, trH = im + trH_off, trX = im + trX_off;
-    Frag3 Af[MT];
-#pragma unroll
-    for (int a2 = 0; a2 < MT; ++a2)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) Af[a2].p[pl] = tr_frag(trA + pl * PLANE_H + a2 * 32, ROW_H);
-    auto load_b = [&](int ct, Frag3& bf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        bf.p[pl] = (ct < NFT) ? tr_frag(trX + pl * PLANE_X + ct * 32, ROW_X)
-                              : tr_frag(trH + pl * PLANE_H + (ct - NFT) * 32, ROW_H);
-    };
-    Frag3 Bf[2];
-    load_b(C0, Bf[0]);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int ct = C0 + j;
-      if (j + 1 < 5) load_b(ct + 1, Bf[(j + 1) & 1]);          // one column tile ahead
-#pragma unroll
-      for (int a2 = 0; a2 < MT; ++a2) {
-        if (ct < NFT) accW[a2][ct] = mfma6(Af[a2], Bf[j & 1], accW[a2][ct]);
-        else accU[a2][ct - NFT] = mfma6(Af[a2], Bf[j & 1], accU[a2][ct - NFT]);
-      }
-      between(j);                                              // a slice of VALU work beside these MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // One pipelined iteration (see the header).  dpo holds the planes of d_pre_{t+1} on entry and
-  // receives those of d_pre_{t-1}; (eo, xr) are the operands of EW(t-1), requested an iteration ago;
-  // (e_load, x_load) receive those of EW(t-2).  EVEN = (t & 1) == 0.
-#ifdef FASTGRNN_DIAG_STAMPS
-  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
-#endif
-  auto iter = [&](auto last_tag, auto even_tag, int t, Frag3& dpo, const EwOps& eo, EwOps& e_load, const XRaw& xr,
-                  XRaw& x_load) __attribute__((always_inline)) {
-    constexpr bool LAST = decltype(last_tag)::value, EVEN = decltype(even_tag)::value;
-    // B operand of the chain: planes of d_pre_t for all units
-    const unsigned char* im = &S.img[t & 3][0];
-    Frag3 dB[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        dB[s].p[p] = *reinterpret_cast<const u32x4*>(im + OFF_DP + p * PLANE_H + i * ROW_H + (32 * s + 8 * g) * 2);
-    __builtin_amdgcn_sched_barrier(0);
-    SPLIT_STAMP(0)
-    if (!LAST) {
-      load_xraw(t >= 2 ? t - 2 : 0, x_load);
-      load_ew(t >= 2 ? t - 2 : 0, e_load);
-    }
-    // ---- d_h chain (.cu:537): C-in = z*g; the VALU meanwhile prepares what EW(t-1) can know
-    //      without d_old_h and publishes the planes of h_{t-2}, x_{t-1}
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) dh[mt] = mfma6(UTf[mt][s], dB[s], dh[mt]);
-    EwPre fpre;
-    if constexpr (!LAST) {
-      f32x4 hpv[MT];
-      ew_pre(eo, fpre, hpv);
-      ew_hx(t - 1, hpv, xr);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SPLIT_STAMP(1)
-    if (t + 2 < Tn) finish_dx(t + 2);               // published in the previous iteration
-    SPLIT_STAMP(5)
-    // d_x(t+1): register-only MFMAs, matrix-pipe filler for the VALU-bound region below (must read dpo
-    // before the last slice overwrites it with the planes of d_pre_{t-1})
-    if (t + 1 < Tn) dx_partial(t + 1, dpo);
-    SPLIT_STAMP(2)
-    // five column tiles x 12 independent MFMAs on the matrix pipe; between them the VALU finishes
-    // EW(t-1): two elements per tile, then the d_pre planes
-    EwState st;
-    auto pieces = [&](int j) __attribute__((always_inline)) {
-      if (!LAST) {
-        if (j < 4) { ew_post(2 * j, eo, fpre, st); ew_post(2 * j + 1, eo, fpre, st); }
-        else ew_publish_dp(t - 1, st, dpo);
-      }
-    };
-    const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
-    if constexpr (EVEN) {
-      weight_grads(std::integral_constant<int, 0>{}, t + 1, pieces);            // pair (t+1, t), tiles 0..4
-    } else {
-      if (t + 2 <= top) weight_grads(std::integral_constant<int, 1>{}, t + 2, pieces);   // pair (t+2, t+1), tiles 5..9
-      else {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) pieces(j);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SPLIT_STAMP(3)
-    lds_barrier();
-    SPLIT_STAMP(4)
-  };
-
-  Frag3 dpoE, dpoO;             // planes of d_pre_s for even / odd s
-  EwOps eE, eO;                 // operands of EW(s) for even / odd s
-  XRaw xE, xO;
-  {
-    EwState st;
-    EwPre f;
-    f32x4 hpv[MT];
-    if ((Tn - 1) & 1) {
-      load_ew(Tn - 1, eO); load_xraw(Tn - 1, xO);
-      if (Tn >= 2) { load_ew(Tn - 2, eE); load_xraw(Tn - 2, xE); }
-      ew_pre(eO, f, hpv); ew_hx(Tn - 1, hpv, xO);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ew_post(k, eO, f, st);
-      ew_publish_dp(Tn - 1, st, dpoO);
-    } else {
-      load_ew(Tn - 1, eE); load_xraw(Tn - 1, xE);
-      if (Tn >= 2) { load_ew(Tn - 2, eO); load_xraw(Tn - 2, xO); }
-      ew_pre(eE, f, hpv); ew_hx(Tn - 1, hpv, xE);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ew_post(k, eE, f, st);
-      ew_publish_dp(Tn - 1, st, dpoE);
-    }
-  }
-  __syncthreads();              // also orders the zeroed virtual-step images
-  {
-    // iteration t: d_x(t+1) from dpo[(t+1)&1]; EW(t-1) with e[(t-1)&1], x[(t-1)&1] -> dpo[(t-1)&1];
-    // requests the operands of EW(t-2) into e[t&1], x[t&1]
-    int t = Tn - 1;
-    if ((t & 1) && t >= 1) { iter(std::false_type{}, std::false_type{}, t, dpoE, eE, eO, xE, xO); --t; }
-    for (; t >= 2; t -= 2) {
-      iter(std::false_type{}, std::true_type{}, t, dpoO, eO, eE, xO, xE);
-      iter(std::false_type{}, std::false_type{}, t - 1, dpoE, eE, eO, xE, xO);
-    }
-    iter(std::true_type{}, std::true_type{}, 0, dpoO, eO, eE, xO, xE);
-  }
-#ifdef FASTGRNN_DIAG_STAMPS
-  if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
-#endif
-  dx_partial(0, dpoE);
-  weight_grads(std::integral_constant<int, 1>{}, 1, [&](int) __attribute__((always_inline)) {});   // pair (1, 0), tiles 5..9
-  if (1 < Tn) finish_dx(1);
-  lds_barrier();
-  finish_dx(0);
-  // ---- flush ---------------------------------------------------------------------------------
-  if (valid) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
-  }
-  // dU / dW slabs: D row 4g+r of tile a is n = 32wv + 16a + 4g + r; column = 16c + i
-  {
-    float* pu = part + (size_t)blockIdx.x * SLAB;
-    float* pw = pu + H * H;
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = wv * 32 + a * 16 + 4 * g + r;
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) pu[(size_t)n * H + c * 16 + i] = accU[a][c][r];
-#pragma unroll
-        for (int f2 = 0; f2 < NFT; ++f2) pw[(size_t)n * F + f2 * 16 + i] = accW[a][f2][r];
-      }
-  }
-  // bias partials: sum over the 16 utterance lanes of each group
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a = sbz[mt][r], c = sbh[mt][r];
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
-      if (i == 0) {
-        float* pb = part + (size_t)blockIdx.x * SLAB + H * H + H * F;
-        pb[n0 + 4 * mt + r] = a;
-        pb[H + n0 + 4 * mt + r] = c;
-      }
-    }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
-  if (l == 0) { S.red[wv] = pz; S.red[4 + wv] = pn; }
-  __syncthreads();
-  if (tid == 0) {
-    float* pzn = part + (size_t)blockIdx.x * SLAB + H * H + H * F + 2 * H;
-    pzn[0] = S.red[0] + S.red[1] + S.red[2] + S.red[3];
-    pzn[1] = S.red[4] + S.red[5] + S.red[6] + S.red[7];
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // backward, 8 waves  (H = 128, F = 32)
 // ------------------------------------------------------------------------------------------
-// Same arithmetic, plane images and step pairing as bwd_scan_split, on a workgroup of 8 waves (two per
-// SIMD), so that a wave stalled on a dependent MFMA, an LDS round trip or a transcendental leaves its
-// SIMD to the other wave, and no wave needs more than 256 registers (no AGPR<->VGPR traffic):
+// Reverse scan on a workgroup of 8 waves (two per SIMD), so that a wave stalled on a dependent MFMA, an LDS
+// round trip or a transcendental leaves its SIMD to the other wave, and no wave needs more than 256
+// registers (no AGPR<->VGPR traffic).  PREACT: aux0 holds the pre-activation W x + U h saved by the forward
+// (one tensor) and z, c are recomputed here; otherwise aux0 = z_s, aux1 = h_prime_s (the reference
+// operator's tensors).  (An earlier 4-wave shape, one wave per SIMD with every fragment streamed through a
+// two-deep register pipeline, was 9-11 % slower and is gone: it could not be written to the operand rule of
+// DESIGN.md section 4.0.)
 //   recurrence   wave w owns ONE 16-unit row tile (units 16w..16w+15, 4 per lane): chain of 24 MFMAs,
 //                EW of 4 elements, planes of its d_pre / h_prev slice and of one feature value per lane
 //   d_x          wave w: feature tile w&1, K-step w>>1 (6 MFMAs); the four partials of a tile meet in
@@ -1133,7 +819,13 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void bwd_scan_split(
 //                t, waves 4-7 pair (t+2, t+1) on odd t: every iteration each SIMD has one wave with 60
 //                independent MFMAs in flight and one with only the recurrence.
 struct BwdW8Lds {
-  unsigned char img[4][IMG];           // as BwdSplitLds::img
+  // Per step s, buffer s&3: natural [utterance][unit] images of the exact bf16 planes of d_pre_s,
+  // h_{s-1} and x_s.  Each is read two ways: as MFMA B fragments (ds_read_b128: 8 consecutive units
+  // of one utterance, the chain) and transposed (ds_read_b64_tr_b16: 8 consecutive utterances of
+  // one unit) for the K = utterance products dW, dU.  The MFMA's K is 32 and a tile has 16
+  // utterances, so dW/dU contract TWO consecutive steps per MFMA (lane groups 0,1 = step s+1,
+  // groups 2,3 = step s); four buffers keep a pair readable for the two iterations that share it.
+  unsigned char img[4][IMG];
   f32x4 DX[2][8][64];                  // d_x partial of wave w: feature tile w&1, K-step w>>1
   float bias[2][128];                  // bias_gate | bias_update (PREACT: the gates are recomputed)
   float red[16];
@@ -1275,18 +967,11 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   };
   // planes of 4 fp32 values -> 8 bytes per plane at byte offset off of the three planes of one image part
   auto put4 = [&](unsigned char* base, int plane_stride, unsigned off, const f32x4 v) __attribute__((always_inline)) {
-    unsigned b0[4], b1[4], b2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b0[j] = fbits(v[j]);
-      const float r1 = v[j] - bitsf(b0[j] & 0xFFFF0000u);
-      b1[j] = fbits(r1);
-      const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
-      b2[j] = fbits(r2);
-    }
-    *reinterpret_cast<uint2*>(base + off) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
-    *reinterpret_cast<uint2*>(base + plane_stride + off) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
-    *reinterpret_cast<uint2*>(base + 2 * plane_stride + off) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
+    uint2 q0, q1, q2;
+    split_quad(v, q0, q1, q2);
+    *reinterpret_cast<uint2*>(base + off) = q0;
+    *reinterpret_cast<uint2*>(base + plane_stride + off) = q1;
+    *reinterpret_cast<uint2*>(base + 2 * plane_stride + off) = q2;
   };
   // EW(t) second half + everything step t publishes: planes of d_pre_t, h_{t-1} (own 4 units) and of one
   // value of x_t.  Leaves dh = z*g, the C-in of chain(t).
@@ -1308,14 +993,11 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     if (RAGGED && !valid) hv = f32x4{0.f, 0.f, 0.f, 0.f};
     put4(im + OFF_HP, PLANE_H, my_row_h, hv);
     {
-      const unsigned a0 = fbits(e.xv);
-      const float r1 = e.xv - bitsf(a0 & 0xFFFF0000u);
-      const unsigned a1 = fbits(r1);
-      const float r2 = r1 - bitsf(a1 & 0xFFFF0000u);
-      const unsigned a2 = fbits(r2);
-      *reinterpret_cast<unsigned short*>(im + OFF_XP + my_x) = (unsigned short)(a0 >> 16);
-      *reinterpret_cast<unsigned short*>(im + OFF_XP + PLANE_X + my_x) = (unsigned short)(a1 >> 16);
-      *reinterpret_cast<unsigned short*>(im + OFF_XP + 2 * PLANE_X + my_x) = (unsigned short)(a2 >> 16);
+      unsigned short s0, s1, s2;
+      split_one(e.xv, s0, s1, s2);
+      *reinterpret_cast<unsigned short*>(im + OFF_XP + my_x) = s0;
+      *reinterpret_cast<unsigned short*>(im + OFF_XP + PLANE_X + my_x) = s1;
+      *reinterpret_cast<unsigned short*>(im + OFF_XP + 2 * PLANE_X + my_x) = s2;
     }
   };
   auto finish_dx = [&](int t) __attribute__((always_inline)) {
@@ -1370,7 +1052,11 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       for (int c = 0; c < NB; ++c)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) acc[a2][C0 + c] = mfma6(Af[a2], Bf[c], acc[a2][C0 + c]);
-      if (acc[0][C0 + NB - 1][0] + acc[1][C0 + NB - 1][0] == 1.2345678e38f) S.red[15] = 1.f;
+      __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks MFMAs below the read)
+      float touch = 0.f;                       // one element of every accumulator of the batch: all have retired
+#pragma unroll
+      for (int c = 0; c < NB; ++c) touch += acc[0][C0 + c][0] + acc[1][C0 + c][0];
+      if (touch == 1.2345678e38f) S.red[15] = 1.f;
       __builtin_amdgcn_sched_barrier(0);
     };
     // batches of 2 + 2 + 1 column tiles: with 3 + 2 the kernel spilled nine registers inside the loop
@@ -1401,8 +1087,10 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     EwPre f;
     auto chain = [&]() __attribute__((always_inline)) {
       // d_h chain (.cu:537), C-in = z*g; d_x partial of step t (.cu:538) from the same fragments
+      f32x4 dlo = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) dh = mfma6(UTf[s2], dB[s2], dh);
+      for (int s2 = 0; s2 < KS; ++s2) mfma6_hl(UTf[s2], dB[s2], dh, dlo);
+      dh += dlo;
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2)                // (a runtime index would put the fragments in scratch)
         if (xks == s2) S.DX[t & 1][wv][l] = mfma6(WTf, dB[s2], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -1547,16 +1235,9 @@ template <int GATE>
 void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                      const void* a0, const void* a1, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
   const int nwg = (d.B + 15) / 16;
-  dim3 grid(nwg), block(256);
+  dim3 grid(nwg);
   const bool ragged = (d.B % 16) != 0, preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   float* part = reinterpret_cast<float*>(ws);
-  auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d), (const float*)ghs,
-                       (const float*)x, (const float*)hs,
-                       (const float*)a0, (const float*)a1, (const float*)h0, (const float*)p.w, (const float*)p.u,
-                       (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
-                       (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
-  };
   auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
     hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
                        (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)ghs,
@@ -1565,19 +1246,13 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
   };
-  // 8-wave kernel for the one-saved-tensor contract (9-11 % faster in the same run); with the reference
-  // operator's (z_s, h_prime_s) pair its extra operand set costs more registers than it gains
+  // FASTGRNN_FLAG_BWD_4WAVE is accepted and ignored: the 4-wave backward it used to select is retired
   if (d.dtype == FASTGRNN_BF16_IO) {
-    block = dim3(512);
     if (ragged) go8(bwd_scan_split_w8<GATE, true, true, true>); else go8(bwd_scan_split_w8<GATE, true, false, true>);
-  } else if (GATE <= FASTGRNN_NL_TANH && !(d.flags & FASTGRNN_FLAG_X_BFT) && ((d.flags & FASTGRNN_FLAG_BWD_4WAVE) || !preact)) {
-    if constexpr (GATE <= FASTGRNN_NL_TANH) {
-      if (preact) { if (ragged) go(bwd_scan_split<GATE, true, true>); else go(bwd_scan_split<GATE, true, false>); }
-      else        { if (ragged) go(bwd_scan_split<GATE, false, true>); else go(bwd_scan_split<GATE, false, false>); }
-    }
-  } else {
-    block = dim3(512);
+  } else if (preact) {
     if (ragged) go8(bwd_scan_split_w8<GATE, true, true>); else go8(bwd_scan_split_w8<GATE, true, false>);
+  } else {
+    if (ragged) go8(bwd_scan_split_w8<GATE, false, true>); else go8(bwd_scan_split_w8<GATE, false, false>);
   }
   const int ntot = 128 * 128 + 128 * 32 + 2 * 128 + 2;
   hipLaunchKernelGGL(reduce_slabs_split, dim3((ntot + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
@@ -1823,18 +1498,11 @@ __global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __re
   };
   auto split4 = [&](const f32x4 v, unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned off)
       __attribute__((always_inline)) {
-    unsigned b0[4], b1[4], b2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b0[j] = fbits(v[j]);
-      const float r1 = v[j] - bitsf(b0[j] & 0xFFFF0000u);
-      b1[j] = fbits(r1);
-      const float r2 = r1 - bitsf(b1[j] & 0xFFFF0000u);
-      b2[j] = fbits(r2);
-    }
-    *reinterpret_cast<uint2*>(p0 + off) = uint2{pack_hi(b0[0], b0[1]), pack_hi(b0[2], b0[3])};
-    *reinterpret_cast<uint2*>(p1 + off) = uint2{pack_hi(b1[0], b1[1]), pack_hi(b1[2], b1[3])};
-    *reinterpret_cast<uint2*>(p2 + off) = uint2{pack_hi(b2[0], b2[1]), pack_hi(b2[2], b2[3])};
+    uint2 q0, q1, q2;
+    split_quad(v, q0, q1, q2);
+    *reinterpret_cast<uint2*>(p0 + off) = q0;
+    *reinterpret_cast<uint2*>(p1 + off) = q1;
+    *reinterpret_cast<uint2*>(p2 + off) = q2;
   };
   auto publish = [&]() __attribute__((always_inline)) {
 #pragma unroll

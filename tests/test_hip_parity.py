@@ -63,7 +63,7 @@ def _check_grads(g, ref, tol, tag):
         # d_zeta / d_nu are ONE scalar each: a sum of T*B*H random-sign terms, i.e. |sum| is
         # ~sqrt(N) times smaller than the sum of magnitudes and an fp32 accumulation (the
         # reference's included) is only good to ~sqrt(N) * 6e-8 relative to it
-        lim = max(tol, 1e-4) if (k in ("d_zeta", "d_nu") and g[k].dtype != np.float64) else tol
+        lim = max(tol, 5e-5) if (k in ("d_zeta", "d_nu") and g[k].dtype != np.float64) else tol
         assert err <= lim, (tag, k, err)
 
 
@@ -751,9 +751,10 @@ def test_module_takes_the_trainers_permuted_view():
 
 @pytest.mark.parametrize("B", [48, 37])
 def test_ab_kernel_variants_agree_with_the_default(B):
-    """The A/B flags select older kernel shapes / operand formats of the same arithmetic: 4-wave forward (8),
-    three-bf16-plane forward state product (64), 4-wave backward (32).  They must agree with the default
-    kernels to fp32 rounding (they differ in summation order and, for 64, in the operand split)."""
+    """The A/B flags select an older kernel shape / operand format of the same arithmetic: 4-wave forward (8),
+    three-bf16-plane forward state product (64).  They must agree with the default kernels to fp32 rounding
+    (they differ in summation order and, for 64, in the operand split).  32 (the retired 4-wave backward) is
+    accepted and ignored."""
     T, F, H = 40, 32, 128
     SAVE_PREACT, FWD_4WAVE, BWD_4WAVE, FWD_BF16X3 = 4, 8, 32, 64
     p = O.make_params(F, H, seed=12, randomize_scalars=True)
@@ -776,5 +777,5 @@ def test_ab_kernel_variants_agree_with_the_default(B):
         got = run(SAVE_PREACT | extra)
         for k, (a, b) in enumerate(zip(ref, got)):
             scale = max(1.0, float(a.abs().max()))
-            tol = 2e-3 if k in (5, 6) else 2e-5           # d_zeta, d_nu: ill-conditioned scalar sums
+            tol = 1e-4 if k in (5, 6) else 2e-5           # d_zeta, d_nu: scalar sums over T*B*H terms
             assert float((a - b).abs().max()) / scale <= tol, (extra, k)
