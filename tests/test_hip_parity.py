@@ -467,7 +467,10 @@ def test_run_to_run_bitwise_repeatability():
     landing in a register that an in-flight MFMA still reads (seen while prototyping a two-role
     backward)."""
     T, F = 99, 32
-    for (H, r, B) in ((128, 0, 1024), (256, 16, 512)):
+    # (H, rank, B, flags): 8-wave kernels under both saved-tensor contracts, the low-rank pair, the 4-wave
+    # forward (8) and the fp32-MFMA path (2)
+    for (H, r, B, flags) in ((128, 0, 1024, 4), (256, 16, 512, 4), (128, 0, 1008, 0), (128, 0, 1024, 4 | 8),
+                             (128, 0, 512, 2), (256, 16, 512, 0)):
         p = O.make_params(F, H, r or None, r or None, seed=21)
         P = _param_tensors(p)
         g = torch.Generator().manual_seed(3)
@@ -477,17 +480,17 @@ def test_run_to_run_bitwise_repeatability():
         first = None
         for rep in range(12):
             outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"],
-                                                h0, 0, P["w1"], P["w2"], P["u1"], P["u2"], flags=4)
+                                                h0, 0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
             aux2 = outs[2] if len(outs) > 2 else outs[1]
             gr = fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], aux2, h0,
-                                               P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=4,
+                                               P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags,
                                                bias_gate=P["bias_gate"], bias_update=P["bias_update"])
             allo = [o for o in list(outs) + list(gr) if o.numel()]
             if first is None:
                 first = [o.clone() for o in allo]
             else:
                 for k, (a, b) in enumerate(zip(allo, first)):
-                    assert torch.equal(a, b), (H, r, rep, k)
+                    assert torch.equal(a, b), (H, r, flags, rep, k)
 
 
 @pytest.mark.parametrize("B,preact", [(37, True), (64, True), (48, False), (1, True)])
