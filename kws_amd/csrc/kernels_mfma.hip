@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int r = 0; r < 4; ++r) hB[4 * q + r] = v[r];
     }
+    // the state reads are issued before the first MFMA: each gets registers of its own (left alone the compiler
+    // issues W.x first and lands them in the feature registers those MFMAs read; operand rule)
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -250,6 +253,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     store_step(Tn - 1, gb);
   } else {
     store_step(Tn - 1, ga);
+  }
+  // The weight registers stay allocated through the last step (its state reads would otherwise be streamed
+  // through them, right behind the MFMAs that read them).  hown comes from the last accumulators: retired.
+  {
+    float tie = hown[0][0];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int kk = 0; kk < KH; kk += 8)
+        asm volatile("" : "+v"(tie) : "v"(Uf[mt][kk]), "v"(Uf[mt][kk + 1]), "v"(Uf[mt][kk + 2]), "v"(Uf[mt][kk + 3]),
+                     "v"(Uf[mt][kk + 4]), "v"(Uf[mt][kk + 5]), "v"(Uf[mt][kk + 6]), "v"(Uf[mt][kk + 7]));
+#pragma unroll
+      for (int kk = 0; kk < KX; kk += 4)
+        asm volatile("" : "+v"(tie) : "v"(Wf[mt][kk]), "v"(Wf[mt][kk + 1]), "v"(Wf[mt][kk + 2]), "v"(Wf[mt][kk + 3]));
+    }
   }
 #ifdef FASTGRNN_DIAG_STAMPS
   if ((DIAG & 16) && blockIdx.x == 7 && l == 0) {
