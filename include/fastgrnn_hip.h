@@ -99,6 +99,14 @@ typedef enum fastgrnn_nonlinearity {
 #define FASTGRNN_FLAG_FWD_BF16X3 64u
 /* Retired: selected an older 4-wave backward kernel; accepted and ignored (the 8-wave backward always runs). */
 #define FASTGRNN_FLAG_BWD_4WAVE 32u
+/* SURVEY 8(f) N2 -- the classifier's view of the LAST layer (model.py:227 reads hs[T-1] alone):
+ *   GRAD_LAST  backward_unroll: grad_hs is [B,H], the gradient of the last state; every other step's is zero and
+ *              is neither materialised nor read (a dense zero [T,B,H] is what autograd would otherwise write and the
+ *              kernel read: 2 x 208 MB at B=4096).  hs, the saved tensors and every output keep their shapes.
+ *   HS_LAST    forward_unroll (inference: z_s must be NULL): hs is [B,H] and receives h_T only.
+ * Both: dense H=128/F=32 (8-wave kernels), any sequence layout; FASTGRNN_ERR_UNSUPPORTED otherwise. */
+#define FASTGRNN_FLAG_GRAD_LAST 256u
+#define FASTGRNN_FLAG_HS_LAST 512u
 
 /* Problem descriptor.  T = 1 for the single-step operators. */
 typedef struct fastgrnn_desc {

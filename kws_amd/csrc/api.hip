@@ -91,9 +91,10 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   if (!x || !h0 || !hs) return FASTGRNN_ERR_NULL_POINTER;
-  if (((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) || d->dtype == FASTGRNN_BF16_IO) &&
-      pick_path(d, 0) != 2)
+  if (((d->flags & (FASTGRNN_FLAG_SAVE_PREACT | FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST)) ||
+       d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 0) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
+  if ((d->flags & FASTGRNN_FLAG_HS_LAST) && z_s) return FASTGRNN_ERR_UNSUPPORTED;   // nothing is saved for a backward
   if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_forward_workspace_bytes(d)))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (pick_path(d, 0)) {
@@ -110,7 +111,7 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   if (st) return st;
   if ((st = check_params(d, p))) return st;
   const bool preact = (d->flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  if ((preact || (d->flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
+  if ((preact || (d->flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_GRAD_LAST)) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if (!grad_hs || !x || !hs || !z_s || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
   if (!g->d_x || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)

@@ -424,7 +424,7 @@ constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide 
 
 template <int GATE, int AUX, bool RAGGED, bool BF = false, bool F16H = true>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
-    int Tn, int B, int rsT, int rsB, int xbft, const float* __restrict__ x, const float* __restrict__ h0,
+    int Tn, int B, int rsT, int rsB, int mode, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
@@ -440,6 +440,8 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
   const int n0 = wv * 16 + g * 4;                  // this lane's 4 hidden units
+  // mode bit 0: x is the trainer's [B,F,T]; bit 1 (FASTGRNN_FLAG_HS_LAST, AUX == 0 only): hs is [B,H], h_T alone
+  const bool xbft = (mode & 1) != 0, hs_last = AUX == 0 && (mode & 2) != 0;
   // feature element this lane converts each step: utterance xu, feature xf
   const int xu = tid >> 5, xf = tid & 31;
   const int xb = blockIdx.x * 16 + xu;
@@ -518,8 +520,9 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     return BF ? bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[e]) : x[e];
   };
   auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
+    if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
     if (valid) {
-      const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
+      const size_t o = hs_last ? (size_t)b * H + n0 : ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
       if (BF) st4_bf16(reinterpret_cast<unsigned short*>(hs) + o, hown); else st4(hs + o, hown);
       if (AUX == 2) st4(zs + o, aux);               // the saved pre-activation stays fp32
     }
@@ -833,7 +836,7 @@ struct BwdW8Lds {
 
 template <int GATE, bool PREACT, bool RAGGED, bool BF = false>
 __global__ __launch_bounds__(512) void bwd_scan_split_w8(
-    int Tn, int B, int rsT, int rsB, int xbft, const float* __restrict__ ghs, const float* __restrict__ x,
+    int Tn, int B, int rsT, int rsB, int mode, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
     const float* __restrict__ h0, const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
@@ -846,6 +849,9 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
 #endif
 
+  // mode bit 0: x / d_x are the trainer's [B,F,T]; bit 1 (FASTGRNN_FLAG_GRAD_LAST): ghs is [B,H], the gradient of
+  // the last state alone (the classifier head reads hs[T-1] only, model.py:227) -- every other step's is zero
+  const bool xbft = (mode & 1) != 0, g_last = (mode & 2) != 0;
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, i = l & 15, g = l >> 4;
@@ -919,13 +925,15 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     e.a0 = ld4(aux0 + o);
     if (!PREACT) e.a1 = ld4(aux1 + o);
     const size_t ex = xbft ? ((size_t)xbc * F + xf) * Tn + t : ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf;
+    const size_t og = g_last ? (size_t)bc * H + n0 : o;
+    const bool g_zero = g_last && t != Tn - 1;       // wave-uniform
     if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
-      e.graw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + o);
+      e.graw = g_zero ? uint2{0u, 0u} : *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + og);
       e.hraw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(hs) + (t == 0 ? o : o - (size_t)rsT * H));
       e.xraw = reinterpret_cast<const unsigned short*>(x)[ex];
     } else {
       const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
-      e.g = ld4(ghs + o);
+      e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(ghs + og);
       e.h = ld4(hprev);
       e.xv = x[ex];
     }
@@ -1240,7 +1248,7 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   float* part = reinterpret_cast<float*>(ws);
   auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
     hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
-                       (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)ghs,
+                       ((d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0) | ((d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 2 : 0), (const float*)ghs,
                        (const float*)x, (const float*)hs,
                        (const float*)a0, (const float*)a1, (const float*)h0, (const float*)p.w, (const float*)p.u,
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
@@ -1691,7 +1699,7 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   };
   auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
     hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
-                       (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)x, (const float*)h0, (const float*)p.w,
+                       ((d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0) | ((d.flags & FASTGRNN_FLAG_HS_LAST) ? 2 : 0), (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
@@ -1701,14 +1709,14 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
     else          { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, true>); else go8(fwd_scan_split_w8<GATE, 0, false, true>); }
     return;
   }
-  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
+  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST)) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
     block = dim3(512);
     if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true, false, false>); else go8(fwd_scan_split_w8<GATE, 1, false, false, false>); }
     else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, false, false>); else go8(fwd_scan_split_w8<GATE, 2, false, false, false>); }
     else               { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, false, false>); else go8(fwd_scan_split_w8<GATE, 0, false, false, false>); }
     return;
   }
-  if (GATE > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
+  if (GATE > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST)) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
     block = dim3(512);
     if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true>); else go8(fwd_scan_split_w8<GATE, 1, false>); }
     else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true>); else go8(fwd_scan_split_w8<GATE, 2, false>); }
@@ -1754,6 +1762,11 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   // quantised gates (rnn.py:53-60) and the [B,F,T] input layout: 8-wave dense kernels only, i.e. the backward
   // under the SAVE_PREACT contract
   if (d.gate_nl > FASTGRNN_NL_TANH || (d.flags & FASTGRNN_FLAG_X_BFT)) return dense && (direction == 0 || preact);
+  // last-state-only outputs / gradients (the classifier's view of the last layer, model.py:227): 8-wave dense kernels
+  if (d.flags & (FASTGRNN_FLAG_GRAD_LAST | FASTGRNN_FLAG_HS_LAST)) {
+    if (!dense) return false;
+    if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
+  }
   // bf16 sequences: dense shape only; the backward only under the SAVE_PREACT contract (8-wave kernel)
   if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || preact);
   // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style

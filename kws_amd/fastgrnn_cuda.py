@@ -174,8 +174,12 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     dev = input.device
     oshape = ((B, T, H) if batch_major else (T, B, H)) if unrolled else (B, H)
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
+    hs_last = bool(unrolled and (flags & _lib.FLAG_HS_LAST))
+    if hs_last and (want_gates or preact):
+        raise RuntimeError("FLAG_HS_LAST is an inference mode: nothing can be saved for a backward "
+                           "(want_gates=False and no FLAG_SAVE_PREACT)")
     with torch.cuda.device(dev):
-        hs = torch.empty(oshape, dtype=input.dtype, device=dev)
+        hs = torch.empty((B, H) if hs_last else oshape, dtype=input.dtype, device=dev)
         zs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates or preact) else None
         cs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates and not preact) else None
         if preact and desc.w_rank and desc.u_rank:
@@ -220,7 +224,9 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
             T, B, F = input.shape
         H = grad_h.shape[-1]
         lead = (B, T) if flags & _lib.FLAG_BATCH_MAJOR else (T, B)
-        _expect(grad_h, lead + (H,), "grad_h"); _expect(hs_or_old_h, lead + (H,), "hidden_states")
+        # FLAG_GRAD_LAST: the gradient of the last state only (the classifier head's view, model.py:227)
+        _expect(grad_h, (B, H) if flags & _lib.FLAG_GRAD_LAST else lead + (H,), "grad_h")
+        _expect(hs_or_old_h, lead + (H,), "hidden_states")
         _expect(z, lead + (H,), "z"); _expect(h_prime, lead + (H,), "h_prime"); _expect(h0, (B, H), "initial_h")
     else:
         T = 1

@@ -68,9 +68,12 @@ class FastGRNNUnrollFunction(Function):
 
     @staticmethod
     def forward(ctx, input, bias_gate, bias_update, zeta, nu, old_h, w, u, w1, w2, u1, u2, gate_non_linearity,
-                batch_major=False):
+                batch_major=False, last_state=False):
         """``batch_major`` (not in the reference signature): ``input`` / the result are [B,T,.] and the
-        kernels index them in place (FLAG_BATCH_MAJOR) instead of working on transposed copies."""
+        kernels index them in place (FLAG_BATCH_MAJOR) instead of working on transposed copies.
+        ``last_state``: return h_T [B,H] alone -- what the classifier head reads
+        (model.py:227) -- so that the backward receives a [B,H] gradient instead of the dense, all-but-one-
+        step-zero [T,B,H] tensor autograd builds for ``hs[-1]`` (FLAG_GRAD_LAST: not written, not read)."""
         old_h = old_h.contiguous()
         if batch_major:
             B, T, F = input.shape
@@ -110,25 +113,39 @@ class FastGRNNUnrollFunction(Function):
         ctx.save_for_backward(*variables)
         ctx.gate_non_linearity = gate_non_linearity
         ctx.preact = preact
+        ctx.last_state = bool(last_state)
+        if last_state:
+            ctx.grad_last = (input.is_cuda and fastgrnn_cuda.kernel_path(
+                T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1, flags | _lib.FLAG_GRAD_LAST) == 2)
+            return (hidden_states[:, -1] if batch_major else hidden_states[-1]).clone()
         return hidden_states
 
     @staticmethod
     def backward(ctx, grad_h):
+        flags = ctx.flags
+        if ctx.last_state:
+            if ctx.grad_last:
+                flags |= _lib.FLAG_GRAD_LAST            # the kernel takes the [B,H] gradient as it is
+            else:                                        # other kernel paths: the dense form autograd would build
+                hs_saved = ctx.saved_tensors[1]
+                dense = torch.zeros_like(hs_saved)
+                (dense[:, -1] if flags & _lib.FLAG_BATCH_MAJOR else dense[-1]).copy_(grad_h)
+                grad_h = dense
         if ctx.preact:
             (input, hidden_states, zeta, nu, w, u, pre_s, aux2, bias_gate, bias_update, old_h,
              w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     pre_s, aux2, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
-                                                    flags=ctx.flags, bias_gate=bias_gate,
+                                                    flags=flags, bias_gate=bias_gate,
                                                     bias_update=bias_update)
         else:
             (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     z_s, h_prime_s, old_h, w1, w2, u1, u2,
-                                                    ctx.gate_non_linearity, flags=ctx.flags)
+                                                    ctx.gate_non_linearity, flags=flags)
         if ctx.flags & _lib.FLAG_X_BFT:                 # d_input was produced as [B,F,T]: hand back the [T,B,F] view
             outputs = [outputs[0].permute(2, 0, 1)] + list(outputs[1:])
-        return _as_autograd_grads(outputs, ctx.needs_input_grad) + (None,)
+        return _as_autograd_grads(outputs, ctx.needs_input_grad) + (None, None)
 
 
 def _as_autograd_grads(outputs, needs):
@@ -330,10 +347,14 @@ class FastGRNNCUDA(nn.Module):
         self.device = self.bias_gate.device
         return out
 
-    def forward(self, input, hiddenState=None, cell_state=None):
+    def forward(self, input, hiddenState=None, cell_state=None, last_state=False):
         """input: [timesteps, batch, features] (or [batch, timesteps, features] when
         ``batch_first``); hiddenState: [batch, state_size], zeros if not provided
-        (rnn.py:807-826).  Returns every hidden state, same leading layout as the input."""
+        (rnn.py:807-826).  Returns every hidden state, same leading layout as the input -- or, with
+        ``last_state=True`` (not in the reference signature; the last layer under the classifier head,
+        model.py:227), the final state [batch, state_size] alone: equal to ``forward(...)[-1]`` with the same
+        gradients, without the dense mostly-zero grad_hs on the way back; under ``torch.no_grad()`` the
+        hidden-state sequence is not written at all (FLAG_HS_LAST)."""
         if not input.is_cuda:
             input = input.to(self.device)
         # batch_first: the reference transposes to [T,B,F] and back (rnn.py:812-813,823-825); where the
@@ -355,12 +376,32 @@ class FastGRNNCUDA(nn.Module):
             hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=hdt, device=input.device)
         if not hiddenState.is_cuda:
             hiddenState = hiddenState.to(self.device)
+        if last_state and not torch.is_grad_enabled():
+            out = self._last_state_inference(input, hiddenState, in_place)
+            if out is not None:
+                return out
         result = FastGRNNUnrollFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu,
                                               hiddenState, self.W, self.U, self.W1, self.W2, self.U1, self.U2,
-                                              self._gate_non_linearity, in_place)
-        if self.batch_first is True and not in_place:
+                                              self._gate_non_linearity, in_place, bool(last_state))
+        if self.batch_first is True and not in_place and not last_state:
             return result.transpose(0, 1)
         return result
+
+    def _last_state_inference(self, input, hiddenState, batch_major):
+        """h_T without writing hs[T,B,H] (FLAG_HS_LAST); None where the kernels cannot (other shapes / paths)."""
+        if batch_major:
+            Bn, Tn, Fn = input.shape
+        else:
+            Tn, Bn, Fn = input.shape
+        rw = self.W1.shape[0] if self.W1.numel() else 0
+        ru = self.U1.shape[0] if self.U1.numel() else 0
+        flags = _lib.FLAG_HS_LAST | (_lib.FLAG_BATCH_MAJOR if batch_major else 0)
+        if input.dtype not in (torch.float32, torch.bfloat16) or fastgrnn_cuda.kernel_path(
+                Tn, Bn, Fn, self._hidden_size, rw, ru, self._gate_non_linearity, 2, input.dtype, 0, flags) != 2:
+            return None
+        return fastgrnn_cuda.forward_unroll(input.contiguous(), self.W, self.U, self.bias_gate, self.bias_update,
+                                            self.zeta, self.nu, hiddenState.contiguous(), self._gate_non_linearity,
+                                            self.W1, self.W2, self.U1, self.U2, want_gates=False, flags=flags)[0]
 
     def getVars(self):
         return _get_vars(self)

@@ -93,6 +93,32 @@ def test_argument_validation_without_launch(lib):
     assert st == 1
 
 
+def test_last_state_flags_are_refused_where_no_kernel_implements_them(lib):
+    """FLAG_GRAD_LAST / FLAG_HS_LAST exist on the dense 8-wave kernels only: every other path --
+    and HS_LAST together with tensors saved for a backward -- answers FASTGRNN_ERR_UNSUPPORTED (7) before any
+    launch; path selection reports the same."""
+    null, one = C.c_void_p(None), C.c_void_p(256)
+    pf = _lib.Params(*([one] * 10))
+    UNSUP = 7
+    assert _lib.status_string(UNSUP) != "unknown status"
+    for extra in (_lib.FLAG_FORCE_GENERIC, _lib.FLAG_FORCE_F32_MFMA):
+        d = _desc(B=4, T=3, flags=_lib.FLAG_HS_LAST | extra)
+        assert lib.fastgrnn_hip_forward_unroll(C.byref(d), C.byref(pf), one, one, one, null, null, null, 0, null) == UNSUP
+        d = _desc(B=4, T=3, flags=_lib.FLAG_GRAD_LAST | extra)
+        g = _lib.Grads(*([one] * 12))
+        assert lib.fastgrnn_hip_backward_unroll(C.byref(d), C.byref(pf), one, one, one, one, one, one, C.byref(g),
+                                                null, 0, null) == UNSUP
+    # other shapes (low-rank, odd sizes) have no last-state kernels either
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_GRAD_LAST)), 1) == 2
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_HS_LAST)), 0) == 2
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=256, w_rank=16, u_rank=16, flags=_lib.FLAG_GRAD_LAST | _lib.FLAG_SAVE_PREACT)), 1) != 2
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=64, flags=_lib.FLAG_HS_LAST)), 0) != 2
+    # HS_LAST with a tensor to save
+    d = _desc(B=4, T=3, flags=_lib.FLAG_HS_LAST)
+    assert lib.fastgrnn_hip_forward_unroll(C.byref(d), C.byref(pf), one, one, one, one, null, null, 0, null) == UNSUP
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_HS_LAST | _lib.FLAG_SAVE_PREACT)), 0) != 2
+
+
 def test_module_parameter_layout_matches_reference_classes():
     """rnn.py:782-805: [out,in] shapes and state-dict key names."""
     from kws_amd import FastGRNNCUDA, FastGRNNCUDACell

@@ -782,3 +782,99 @@ def test_ab_kernel_variants_agree_with_the_default(B):
             scale = max(1.0, float(a.abs().max()))
             tol = 1e-4 if k in (5, 6) else 2e-5           # d_zeta, d_nu: scalar sums over T*B*H terms
             assert float((a - b).abs().max()) / scale <= tol, (extra, k)
+
+
+# ---- the classifier's view of the last layer (model.py:227 reads hs[T-1] alone) ---------------
+GRAD_LAST, HS_LAST = 256, 512
+
+
+@pytest.mark.parametrize("B,preact,bf16,batch_major", [(64, True, False, False), (37, True, False, False),
+                                                       (48, False, False, False), (37, True, True, False),
+                                                       (64, True, False, True)])
+def test_grad_last_equals_the_dense_zero_padded_gradient(B, preact, bf16, batch_major):
+    """FLAG_GRAD_LAST: grad_hs is the [B,H] gradient of the last state.  Adding the zero gradient of every
+    other step is exact, so all twelve outputs equal the dense run's bit for bit."""
+    T, F, H = 21, 32, 128
+    p = O.make_params(F, H, seed=31, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(32)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    lead = (B, T) if batch_major else (T, B)
+    x = torch.randn(*lead, F, generator=g).to(DEV).to(dt)
+    gl = torch.randn(B, H, generator=g).to(DEV).to(dt)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    flags = (4 if preact else 0) | (16 if batch_major else 0)
+    outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+    aux2 = outs[2] if len(outs) > 2 else outs[1]
+    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"]) if preact else {}
+    dense = torch.zeros(*lead, H, device=DEV, dtype=dt)
+    (dense[:, -1] if batch_major else dense[-1]).copy_(gl)
+    ref = fastgrnn_cuda.backward_unroll(dense, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], aux2, h0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags, **kw)
+    got = fastgrnn_cuda.backward_unroll(gl, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], aux2, h0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags | GRAD_LAST, **kw)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a.shape == b.shape and torch.equal(a, b), k
+    # and against the oracle (fp32, time-major case only)
+    if not bf16 and not batch_major:
+        hs_o, zs_o, cs_o = O.unroll_forward(x.cpu().numpy(), p, h0.cpu().numpy())
+        G = np.zeros((T, B, H), np.float32); G[-1] = gl.cpu().numpy()
+        ref_o = O.unroll_backward(G, x.cpu().numpy(), hs_o, zs_o, cs_o, p, h0.cpu().numpy())
+        _check_grads({n: o.cpu().numpy() for n, o in zip(["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0",
+                                                           "d_w", "d_u"], got)}, ref_o, 1e-5, "grad_last")
+
+
+@pytest.mark.parametrize("B,bf16,batch_major", [(64, False, False), (37, False, False), (48, True, False), (37, False, True)])
+def test_hs_last_forward_writes_only_the_final_state(B, bf16, batch_major):
+    """FLAG_HS_LAST (inference): hs is [B,H] = h_T, equal to the last row of the full forward bit for bit; with
+    saved tensors requested the combination is refused."""
+    T, F, H = 17, 32, 128
+    p = O.make_params(F, H, seed=33, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(34)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    lead = (B, T) if batch_major else (T, B)
+    x = torch.randn(*lead, F, generator=g).to(DEV).to(dt)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    flags = 16 if batch_major else 0
+    args = (x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])
+    full = fastgrnn_cuda.forward_unroll(*args, want_gates=False, flags=flags)[0]
+    last = fastgrnn_cuda.forward_unroll(*args, want_gates=False, flags=flags | HS_LAST)[0]
+    assert last.shape == (B, H)
+    assert torch.equal(last, full[:, -1] if batch_major else full[-1])
+    with pytest.raises(RuntimeError):
+        fastgrnn_cuda.forward_unroll(*args, want_gates=True, flags=flags | HS_LAST)
+    with pytest.raises(RuntimeError):                 # generic path: unsupported, loudly
+        fastgrnn_cuda.forward_unroll(*args, want_gates=False, flags=flags | HS_LAST | FORCE_GENERIC)
+
+
+@pytest.mark.parametrize("kind", ["dense", "dense_batch_first", "lowrank", "dense_bf16"])
+def test_module_last_state_matches_indexing_the_sequence(kind):
+    """FastGRNNCUDA(..., last_state=True) == FastGRNNCUDA(...)[-1] with the same parameter and input gradients
+    (dense H=128/F=32: FLAG_GRAD_LAST; other shapes: the dense form on the same kernels); under no_grad the
+    sequence is not written (FLAG_HS_LAST)."""
+    from kws_amd.rnn import FastGRNNCUDA
+    T, B, F = 19, 40, 32
+    H, r = (256, 16) if kind == "lowrank" else (128, None)
+    bf = kind == "dense_batch_first"
+    torch.manual_seed(5)
+    m = FastGRNNCUDA(F, H, wRank=r, uRank=r, batch_first=bf, device=DEV)
+    x = torch.randn((B, T, F) if bf else (T, B, F), device=DEV)
+    if kind == "dense_bf16":
+        x = x.to(torch.bfloat16)
+    x1 = x.clone().requires_grad_(True)
+    x2 = x.clone().requires_grad_(True)
+    gl = torch.randn(B, H, device=DEV).to(x.dtype)
+    full = m(x1)
+    (full[:, -1] if bf else full[-1]).backward(gl)
+    g1 = {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    last = m(x2, last_state=True)
+    assert last.shape == (B, H) and torch.equal(last, (full[:, -1] if bf else full[-1]).detach())
+    last.backward(gl)
+    for n, p_ in m.named_parameters():
+        assert torch.equal(g1[n], p_.grad), n
+    assert torch.equal(x1.grad, x2.grad)
+    with torch.no_grad():
+        assert torch.equal(m(x, last_state=True), last.detach())
