@@ -190,6 +190,20 @@ int fastgrnn_hip_backward(const fastgrnn_desc *d, const fastgrnn_params *p,
                           const fastgrnn_grads *g,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- classifier head on the last state ------------------------------------------------------
+ * head_xent -- replaces, for training, the three torch modules the reference chains after the last layer:
+ *   keyword_scores = F.log_softmax(self.hidden2keyword(hs[T-1]), dim=1)     (model.py:86-88, 226-230)
+ *   loss = nn.NLLLoss()(keyword_scores, labels)                              (trainClassifier.py:154,236; mean)
+ * and their backward.  fp32.  h_last:[B,H] (e.g. the FASTGRNN_FLAG_HS_LAST / last_state output), fc_w:[C,H],
+ * fc_b:[C] (nn.Linear layout), labels:[B] int64 in [0,C).  Writes loss[1], log_probs:[B,C] (may be NULL),
+ * d_h_last:[B,H] = dLoss/dh_last, d_fc_w:[C,H], d_fc_b:[C] (overwritten).  Deterministic (fixed-order reduction).
+ * H <= 256, C <= 64, else FASTGRNN_ERR_UNSUPPORTED.  workspace: fastgrnn_hip_head_workspace_bytes(B,H,C). */
+size_t fastgrnn_hip_head_workspace_bytes(int32_t B, int32_t H, int32_t C);
+int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void *h_last, const void *fc_w,
+                           const void *fc_b, const int64_t *labels, void *loss, void *log_probs,
+                           void *d_h_last, void *d_fc_w, void *d_fc_b,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

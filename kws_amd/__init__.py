@@ -5,8 +5,10 @@ there is no CPU path in this package."""
 from . import _lib  # noqa: F401
 from . import fastgrnn_cuda  # noqa: F401
 from . import utils  # noqa: F401
+from . import head  # noqa: F401
+from .head import KeywordHead, keyword_loss  # noqa: F401
 from .rnn import (FastGRNNCUDA, FastGRNNCUDACell, FastGRNNFunction,  # noqa: F401
                   FastGRNNUnrollFunction)
 
-__all__ = ["fastgrnn_cuda", "utils", "FastGRNNCUDA", "FastGRNNCUDACell", "FastGRNNFunction",
-           "FastGRNNUnrollFunction"]
+__all__ = ["fastgrnn_cuda", "utils", "head", "FastGRNNCUDA", "FastGRNNCUDACell", "FastGRNNFunction",
+           "FastGRNNUnrollFunction", "KeywordHead", "keyword_loss"]

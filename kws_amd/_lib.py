@@ -36,6 +36,7 @@ EXPORTS = (
     "fastgrnn_hip_forward_workspace_bytes", "fastgrnn_hip_backward_workspace_bytes",
     "fastgrnn_hip_forward_unroll", "fastgrnn_hip_backward_unroll",
     "fastgrnn_hip_forward", "fastgrnn_hip_backward",
+    "fastgrnn_hip_head_workspace_bytes", "fastgrnn_hip_head_xent",
 )
 
 
@@ -96,6 +97,10 @@ def load():
     lib.fastgrnn_hip_forward.argtypes = [DP, PP, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.fastgrnn_hip_backward.restype = i32
     lib.fastgrnn_hip_backward.argtypes = [DP, PP, vp, vp, vp, vp, vp, GP, vp, sz, vp]
+    lib.fastgrnn_hip_head_workspace_bytes.restype = sz
+    lib.fastgrnn_hip_head_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.fastgrnn_hip_head_xent.restype = i32
+    lib.fastgrnn_hip_head_xent.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     if lib.fastgrnn_hip_abi_version() != ABI_VERSION:
         raise FastGRNNLibraryError("ABI version mismatch: library %d, binding %d"
                                    % (lib.fastgrnn_hip_abi_version(), ABI_VERSION))

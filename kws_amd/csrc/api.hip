@@ -146,4 +146,20 @@ int fastgrnn_hip_backward(const fastgrnn_desc* d, const fastgrnn_params* p, cons
                                       stream);
 }
 
+size_t fastgrnn_hip_head_workspace_bytes(int32_t B, int32_t H, int32_t C) {
+  return head_supported(B, H, C) ? head_ws_bytes(B, H, C) : 0;
+}
+
+int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void* h_last, const void* fc_w, const void* fc_b,
+                           const int64_t* labels, void* loss, void* log_probs, void* d_h_last, void* d_fc_w,
+                           void* d_fc_b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 1 || H < 1 || C < 1) return FASTGRNN_ERR_BAD_SHAPE;
+  if (!head_supported(B, H, C)) return FASTGRNN_ERR_UNSUPPORTED;
+  if (!h_last || !fc_w || !fc_b || !labels || !loss || !d_h_last || !d_fc_w || !d_fc_b) return FASTGRNN_ERR_NULL_POINTER;
+  int st = check_ws(workspace, workspace_bytes, head_ws_bytes(B, H, C));
+  if (st) return st;
+  return head_xent(B, H, C, h_last, fc_w, fc_b, labels, loss, log_probs, d_h_last, d_fc_w, d_fc_b, workspace,
+                   reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

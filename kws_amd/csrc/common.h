@@ -76,4 +76,10 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
                    const void* hs, const void* zs, const void* cs, const void* h0,
                    const fastgrnn_grads& g, void* ws, hipStream_t s);
 
+// classifier head on the last state: Linear + log_softmax + NLL, forward and backward (kernels_head.hip)
+bool head_supported(int B, int H, int C);
+size_t head_ws_bytes(int B, int H, int C);
+int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const void* fc_b, const void* labels,
+              void* loss, void* logp, void* d_h, void* d_w, void* d_b, void* ws, hipStream_t s);
+
 }  // namespace fastgrnn

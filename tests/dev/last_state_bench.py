@@ -51,3 +51,40 @@ for rep in range(2):
     c, d = timed(infer_full), timed(infer_last)
     print("train step  hs[-1].backward: %.1f us   last_state=True: %.1f us   (%.2fx)" % (a, b, a / b))
     print("inference   full sequence:   %.1f us   last_state=True: %.1f us   (%.2fx)" % (c, d, c / d), flush=True)
+
+# ---- the whole classifier tail (model.py:226-230 + trainClassifier.py:236): torch modules vs last_state + fused head
+from kws_amd.head import KeywordHead
+head = KeywordHead(H, 12, device=dev)
+y = torch.randint(0, 12, (B,), device=dev)
+nll = torch.nn.NLLLoss()
+
+
+def tail_reference():
+    m.zero_grad(set_to_none=True); head.zero_grad(set_to_none=True)
+    nll(head(m(x)[-1]), y).backward()
+
+
+def tail_fused():
+    m.zero_grad(set_to_none=True); head.zero_grad(set_to_none=True)
+    head.loss(m(x, last_state=True), y).backward()
+
+
+def head_only_torch():
+    head.zero_grad(set_to_none=True)
+    hl = hlast.detach().requires_grad_(True)
+    nll(head(hl), y).backward()
+
+
+def head_only_fused():
+    head.zero_grad(set_to_none=True)
+    hl = hlast.detach().requires_grad_(True)
+    head.loss(hl, y).backward()
+
+
+with torch.no_grad():
+    hlast = m(x, last_state=True)
+for rep in range(2):
+    a, b = timed(tail_reference), timed(tail_fused)
+    c, d = timed(head_only_torch), timed(head_only_fused)
+    print("layer + head + loss, fwd+bwd   torch tail: %.1f us   last_state + fused head: %.1f us   (%.2fx)" % (a, b, a / b))
+    print("head + loss alone, fwd+bwd     torch: %.1f us   fused: %.1f us" % (c, d), flush=True)

@@ -878,3 +878,65 @@ def test_module_last_state_matches_indexing_the_sequence(kind):
     assert torch.equal(x1.grad, x2.grad)
     with torch.no_grad():
         assert torch.equal(m(x, last_state=True), last.detach())
+
+
+@pytest.mark.parametrize("B,H,Cn", [(64, 128, 12), (37, 128, 12), (4096, 128, 12), (50, 256, 35), (1, 64, 2), (130, 20, 64)])
+def test_classifier_head_loss_and_gradients_vs_torch_cpu(B, H, Cn):
+    """fastgrnn_hip_head_xent == NLLLoss()(log_softmax(Linear(h)), y) and its autograd gradients, computed by
+    torch on the CPU in float64 (model.py:226-230, trainClassifier.py:154,236).  fp32 tolerance 1e-5 relative
+    to the largest element of each tensor."""
+    from kws_amd import head
+    g = torch.Generator().manual_seed(41)
+    h = torch.randn(B, H, generator=g)
+    w = 0.3 * torch.randn(Cn, H, generator=g)
+    b = 0.1 * torch.randn(Cn, generator=g)
+    y = torch.randint(0, Cn, (B,), generator=g)
+    h64, w64, b64 = (t.double().requires_grad_(True) for t in (h, w, b))
+    logp_ref = torch.log_softmax(h64 @ w64.t() + b64, dim=1)
+    loss_ref = torch.nn.NLLLoss()(logp_ref, y)
+    loss_ref.backward()
+    loss, logp, d_h, d_w, d_b = head.head_xent(h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV), want_log_probs=True)
+
+    def close(a, ref, what):
+        ref = ref.detach().float()
+        scale = max(1e-30, float(ref.abs().max()))
+        assert float((a.cpu() - ref).abs().max()) / scale <= 1e-5, what
+
+    close(loss, loss_ref.reshape(1), "loss")
+    close(logp, logp_ref, "log_probs")
+    close(d_h, h64.grad, "d_h")
+    close(d_w, w64.grad, "d_w")
+    close(d_b, b64.grad, "d_b")
+    # twice the same bits (fixed-order reduction)
+    again = head.head_xent(h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV), want_log_probs=True)
+    for a, c in zip((loss, logp, d_h, d_w, d_b), again):
+        assert torch.equal(a, c)
+
+
+def test_model_tail_last_state_plus_head_matches_the_reference_chain():
+    """The tail of RNNClassifierModel.forward + the training loss (model.py:226-230, trainClassifier.py:236) two
+    ways on the GPU: hs = rnn(x); NLLLoss(log_softmax(Linear(hs[-1]))) with torch modules, against
+    rnn(x, last_state=True) -> KeywordHead.loss.  Same loss and same gradients for every parameter and the input."""
+    from kws_amd.rnn import FastGRNNCUDA
+    from kws_amd.head import KeywordHead
+    T, B, F, H, Cn = 25, 96, 32, 128, 12
+    torch.manual_seed(6)
+    rnn = FastGRNNCUDA(F, H, device=DEV)
+    head = KeywordHead(H, Cn, device=DEV)
+    x = torch.randn(T, B, F, device=DEV)
+    y = torch.randint(0, Cn, (B,), device=DEV)
+    x1 = x.clone().requires_grad_(True)
+    loss_ref = torch.nn.NLLLoss()(head(rnn(x1)[-1]), y)
+    loss_ref.backward()
+    params = list(rnn.named_parameters()) + list(head.named_parameters())
+    g_ref = {n: p_.grad.clone() for n, p_ in params}
+    for _, p_ in params:
+        p_.grad = None
+    x2 = x.clone().requires_grad_(True)
+    loss = head.loss(rnn(x2, last_state=True), y)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+    for n, p_ in params:
+        scale = max(1e-12, float(g_ref[n].abs().max()))
+        assert float((p_.grad - g_ref[n]).abs().max()) / scale <= 2e-5, n
+    assert float((x2.grad - x1.grad).abs().max()) / max(1e-12, float(x1.grad.abs().max())) <= 2e-5
