@@ -104,17 +104,30 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
   }
 }
 
-// out[e] = sum over workgroups of part[wg][e], fixed order; e < C*H + C + 1 (d_W | d_b | loss)
+// out[e] = sum over workgroups of part[wg][e], e < C*H + C + 1 (d_W | d_b | loss), in a fixed order: a workgroup
+// owns 32 outputs; its 8 thread rows each sum every 8th workgroup's partial (32 independent loads in flight per
+// thread instead of one dependent chain of nwg), then the 8 row sums are added in row order.
 __global__ __launch_bounds__(256) void head_reduce(int nwg, int n, int CH, int C, const float* __restrict__ part,
                                                    float* __restrict__ d_w, float* __restrict__ d_b,
                                                    float* __restrict__ loss) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  __shared__ float rows[8][32];
+  const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + col;
   float acc = 0.f;
-  for (int w = 0; w < nwg; ++w) acc += part[(size_t)w * n + e];
-  if (e < CH) d_w[e] = acc;
-  else if (e < CH + C) d_b[e - CH] = acc;
-  else loss[0] = acc;
+  if (e < n) {
+#pragma unroll 8
+    for (int w = row; w < nwg; w += 8) acc += part[(size_t)w * n + e];
+  }
+  rows[row][col] = acc;
+  __syncthreads();
+  if (row == 0 && e < n) {
+    float t = rows[0][col];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t += rows[r][col];
+    if (e < CH) d_w[e] = t;
+    else if (e < CH + C) d_b[e - CH] = t;
+    else loss[0] = t;
+  }
 }
 
 size_t head_lds_bytes(int H, int C) {
@@ -144,7 +157,7 @@ int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const v
                      (const float*)fc_w, (const float*)fc_b, (const long long*)labels, 1.0f / (float)B, (float*)logp,
                      (float*)d_h, part);
   const int n = C * H + C + 1;
-  hipLaunchKernelGGL(head_reduce, dim3((n + 255) / 256), dim3(256), 0, s, nwg, n, C * H, C, (const float*)part,
+  hipLaunchKernelGGL(head_reduce, dim3((n + 31) / 32), dim3(256), 0, s, nwg, n, C * H, C, (const float*)part,
                      (float*)d_w, (float*)d_b, (float*)loss);
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
