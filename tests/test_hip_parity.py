@@ -883,8 +883,8 @@ def test_module_last_state_matches_indexing_the_sequence(kind):
 @pytest.mark.parametrize("B,H,Cn", [(64, 128, 12), (37, 128, 12), (4096, 128, 12), (50, 256, 35), (1, 64, 2), (130, 20, 64)])
 def test_classifier_head_loss_and_gradients_vs_torch_cpu(B, H, Cn):
     """fastgrnn_hip_head_xent == NLLLoss()(log_softmax(Linear(h)), y) and its autograd gradients, computed by
-    torch on the CPU in float64 (model.py:226-230, trainClassifier.py:154,236).  fp32 tolerance 1e-5 relative
-    to the largest element of each tensor."""
+    torch on the CPU in float64 (model.py:226-230, trainClassifier.py:154,236) and by the numpy oracle
+    (oracle.head_loss_and_grads).  fp32 tolerance 1e-5 relative to the largest element of each tensor."""
     from kws_amd import head
     g = torch.Generator().manual_seed(41)
     h = torch.randn(B, H, generator=g)
@@ -907,6 +907,9 @@ def test_classifier_head_loss_and_gradients_vs_torch_cpu(B, H, Cn):
     close(d_h, h64.grad, "d_h")
     close(d_w, w64.grad, "d_w")
     close(d_b, b64.grad, "d_b")
+    o = O.head_loss_and_grads(h.double().numpy(), w.double().numpy(), b.double().numpy(), y.numpy())
+    for a, ref, what in zip((loss, logp, d_h, d_w, d_b), o, ("loss", "log_probs", "d_h", "d_w", "d_b")):
+        close(a, torch.from_numpy(np.atleast_1d(np.asarray(ref))), "oracle " + what)
     # twice the same bits (fixed-order reduction)
     again = head.head_xent(h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV), want_log_probs=True)
     for a, c in zip((loss, logp, d_h, d_w, d_b), again):

@@ -94,3 +94,24 @@ def test_oracle_backward_finite_difference(gate, lowrank):
             fd = (lp - lm) / (2 * eps)
             an = g[key].reshape(-1)[i]
             assert abs(fd - an) <= 1e-6 * max(1.0, abs(fd)), (key, i, fd, an)
+
+
+@pytest.mark.parametrize("B,H,C", [(7, 16, 3), (64, 128, 12), (33, 40, 35)])
+def test_head_oracle_matches_torch_modules(B, H, C):
+    """The numpy head (Linear + log_softmax + NLLLoss and gradients) against the torch modules the reference chains
+    (model.py:86-88, 226-230; trainClassifier.py:154,236), float64, autograd gradients."""
+    import torch
+    rng = np.random.default_rng(B + H + C)
+    h = rng.standard_normal((B, H)); W = 0.3 * rng.standard_normal((C, H)); b = 0.1 * rng.standard_normal(C)
+    y = rng.integers(0, C, B)
+    lin = torch.nn.Linear(H, C).double()
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(W)); lin.bias.copy_(torch.from_numpy(b))
+    ht = torch.from_numpy(h).requires_grad_(True)
+    scores = torch.nn.functional.log_softmax(lin(ht), dim=1)
+    loss = torch.nn.NLLLoss()(scores, torch.from_numpy(y))
+    loss.backward()
+    got = O.head_loss_and_grads(h, W, b, y)
+    for a, ref in zip(got, (loss.detach().numpy(), scores.detach().numpy(), ht.grad.numpy(), lin.weight.grad.numpy(),
+                            lin.bias.grad.numpy())):
+        assert np.allclose(a, ref, rtol=1e-12, atol=1e-14)
