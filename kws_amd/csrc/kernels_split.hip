@@ -1539,31 +1539,55 @@ __global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __re
     publish();
     __syncthreads();
     if (r0 + TN_STAGE < r_end) load_stage(r0 + TN_STAGE);
-    // Several waves share a SIMD here (2 workgroups per CU): all of this stage's fragment reads are issued,
-    // into registers of their own, before the first MFMA, and the MFMAs have retired before the next stage
-    // reloads them (see bwd_scan_split_w8::weight_grads).
-    Frag3 fa[TPW], fb[TPW];
+    // Several waves share a SIMD here (2 workgroups per CU): all of a batch's fragment reads are issued,
+    // into registers of their own, before its first MFMA, and the MFMAs have retired before the next batch or
+    // stage reloads them (operand rule).  A wave's tiles wv, wv+4, ... share their B fragment
+    // when NT divides 4 (nt = wv % NT) and their A fragment when MT == 1: those are read once.  Batches of at
+    // most four tiles keep the kernel under 128 registers' worth of fragments (two workgroups per CU).
+    constexpr bool A_CONST = (MT == 1), B_CONST = (4 % NT == 0);
+    constexpr int BATCH = TPW < 4 ? TPW : 4;
+    Frag3 fa1, fb1;
+    if (A_CONST) {
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-      const int tile = wv + 4 * k;
-      if (tile < NTILE) {                            // wave-uniform
-        const int mt = tile / NT, nt = tile % NT;
+      for (int pl = 0; pl < 3; ++pl) fa1.p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA), ROWA);
+    }
+    if (B_CONST) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          fa[k].p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA) + mt * 32, ROWA);
-          fb[k].p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + nt * 32, ROWB);
+      for (int pl = 0; pl < 3; ++pl) fb1.p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + (wv % NT) * 32, ROWB);
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < TPW; k0 += BATCH) {
+      Frag3 fa[BATCH], fb[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int tile = wv + 4 * (k0 + k);
+        if (k0 + k < TPW && tile < NTILE) {            // wave-uniform
+          const int mt = tile / NT, nt = tile % NT;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            if (!A_CONST) fa[k].p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA) + mt * 32, ROWA);
+            if (!B_CONST) fb[k].p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + nt * 32, ROWB);
+          }
         }
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float touch = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      float touch = 0.f;
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-      const int tile = wv + 4 * k;
-      if (tile < NTILE) { acc[k] = mfma6(fa[k], fb[k], acc[k]); touch += acc[k][0]; }
+      for (int k = 0; k < BATCH; ++k) {
+        const int tile = wv + 4 * (k0 + k);
+        if (k0 + k < TPW && tile < NTILE) {
+          acc[k0 + k] = mfma6(A_CONST ? fa1 : fa[k], B_CONST ? fb1 : fb[k], acc[k0 + k]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks MFMAs below the read)
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int tile = wv + 4 * (k0 + k);
+        if (k0 + k < TPW && tile < NTILE) touch += acc[k0 + k][0];
+      }
+      if (touch == 1.2345678e38f) part[0] = 1.f;       // VALU read of every accumulator: the MFMAs have retired
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (touch == 1.2345678e38f) part[0] = 1.f;       // VALU read of every accumulator: the MFMAs have retired
-    __builtin_amdgcn_sched_barrier(0);
   }
   // D row 4g + r of tile (mt, nt) is m = 16mt + 4g + r, column n = 16nt + (l & 15)
   float* pc = part + (size_t)blockIdx.x * M * N;
