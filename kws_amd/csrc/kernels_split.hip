@@ -607,23 +607,27 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
 // forward, low-rank  (H = 256, F = 32, wRank = uRank = 16: BASELINE config 4)
 // ------------------------------------------------------------------------------------------
 // pre = W2 (W1 x) + U2 (U1 h), evaluated factorised like the CPU cell (rnn.py:280-287).  Workgroup =
-// 4 waves = 16 utterances; wave w owns hidden units 64w..64w+63 (four 16-row tiles) and a lane its
-// 16 consecutive units n0..n0+15.  All factor planes are resident in registers.
+// NW waves = 16 utterances; wave w owns hidden units UPW*w .. (NW = 8: 32 units, two 16-row tiles; NW = 4: 64
+// units, four tiles) and a lane its UPW/4 consecutive units.  All factor planes are resident in registers.
 //   A  m_h partial: U1 contracted over the wave's OWN 64 units -- the B operand is the lane's own
 //      two fragments of h, straight from registers (h never goes through LDS); m_x = W1 x.
 //   -  the four partials (and m_x, from wave 0) meet in a 16 KB LDS buffer: ONE barrier per step
 //   B  pre tile = [U2 | W2] . [m_h ; m_x]: K = 16 + 16 = one K-step of 32, four row tiles per wave,
 //      run one after the other so that each tile's epilogue sits under the next tile's MFMAs.
-template <int GATE, int AUX, bool RAGGED>
-__global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
+template <int GATE, int AUX, bool RAGGED, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
     int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ u1, const float* __restrict__ u2,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs) {
-  constexpr int H = 256, F = 32, R = 16, NT = 4, MROW = 36;   // MROW: padded floats per (wave, utterance) row of m
-  __shared__ __attribute__((aligned(16))) float mp[2][4][16][MROW];
+  // NW waves per workgroup (8 = two per SIMD: one wave's VALU epilogue runs beside the other's MFMAs / LDS round
+  // trip; 4 = the first shape, kept for A/B).  UPW units per wave, NT row tiles, KU K-steps of U1 over own units.
+  constexpr int H = 256, F = 32, R = 16, UPW = H / NW, NT = UPW / 16, KU = UPW / 32, UPL = UPW / 4;
+  constexpr int MROW = 36;   // padded floats per (wave, utterance) row of m
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,13 +635,13 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
   const int b = blockIdx.x * 16 + i;
   const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
-  const int n0 = wv * 64 + g * 16;                 // this lane's 16 hidden units
+  const int n0 = wv * UPW + g * UPL;               // this lane's UPL consecutive hidden units
 
   // ---- resident A operands -----------------------------------------------------------------
-  Frag3 U1f[2], W1f, UW2f[NT];
+  Frag3 U1f[KU], W1f, UW2f[NT];
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {                    // rows = rank index i; K-step v = units n0' + 8v + j of lane group g
-    const float* p = u1 + (size_t)i * H + wv * 64 + g * 16 + 8 * v;
+  for (int v = 0; v < KU; ++v) {                   // rows = rank index i; K-step v = units n0 + 8v + j of lane group g
+    const float* p = u1 + (size_t)i * H + n0 + 8 * v;
     U1f[v] = split3(ld4(p), ld4(p + 4));
   }
   {
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
   }
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {                // rows = units; K = [m_h rows 8g.. | m_x rows 8(g-2)..]
-    const int nA = wv * 64 + (i >> 2) * 16 + mt * 4 + (i & 3);
+    const int nA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
     const float* p = (g < 2) ? u2 + (size_t)nA * R + 8 * g : w2 + (size_t)nA * R + 8 * (g - 2);
     UW2f[mt] = split3(ld4(p), ld4(p + 4));
   }
@@ -657,9 +661,9 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
     bhv[mt] = ld4(bh + n0 + 4 * mt);
     hown[mt] = ld4(h0 + (size_t)bc * H + n0 + 4 * mt);
   }
-  Frag3 hfrag[2];
+  Frag3 hfrag[KU];
 #pragma unroll
-  for (int v = 0; v < 2; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
+  for (int v = 0; v < KU; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
 
   struct Feat { f32x4 lo, hi; };
@@ -694,10 +698,10 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
     constexpr bool FIRST = decltype(first_tag)::value;
     // ---- A: rank-space partials ------------------------------------------------------------
     const Frag3 xB = split3(xuse.lo, xuse.hi);
-    f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});
-    mh = mfma6(U1f[1], hfrag[1], mh);                                                   // rnn.py:286 (partial over own units)
-    f32x4 mx = mfma6(W1f, xB, f32x4{0.f, 0.f, 0.f, 0.f});                               // rnn.py:280
-    if (wv != 0) mx = f32x4{0.f, 0.f, 0.f, 0.f};                                        // m_x enters the sum once
+    f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});                      // rnn.py:286 (partial over own units)
+    if constexpr (KU == 2) mh = mfma6(U1f[1], hfrag[1], mh);
+    f32x4 mx = f32x4{0.f, 0.f, 0.f, 0.f};                                               // m_x enters the sum once:
+    if (wv == 0) mx = mfma6(W1f, xB, mx);                                               // wave 0 (uniform branch); rnn.py:280
     if (!FIRST) store_step(t - 1, gprev);
     // lane (b=i, g) holds rows 4g..4g+3 of both 16-row results
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
     // ---- m = sum of the partials; this lane's B fragment is rows 8g..8g+7 of [m_h ; m_x] -------
     f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
 #pragma unroll
-    for (int w2i = 0; w2i < 4; ++w2i) {
+    for (int w2i = 0; w2i < NW; ++w2i) {
       mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
       mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
     }
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(256) void fwd_scan_lowrank_split(
       gout.z[NT - 1][r] = (AUX == 2) ? pre : z; gout.c[NT - 1][r] = c;
     }
 #pragma unroll
-    for (int v = 0; v < 2; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
+    for (int v = 0; v < KU; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
   };
 
   Feat xa, xb;
@@ -1757,7 +1761,7 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
 template <int GATE>
 void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
                              void* zs, void* cs, hipStream_t s) {
-  dim3 grid((d.B + 15) / 16), block(256);
+  dim3 grid((d.B + 15) / 16), block(512);
   const bool ragged = (d.B % 16) != 0;
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w1,
@@ -1766,6 +1770,13 @@ void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                        (float*)cs);
   };
   const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
+  if (d.flags & FASTGRNN_FLAG_FWD_4WAVE) {             // A/B: the first shape, four waves of 64 units
+    block = dim3(256);
+    if (aux == 1)      { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true, 4>); else go(fwd_scan_lowrank_split<GATE, 1, false, 4>); }
+    else if (aux == 2) { if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true, 4>); else go(fwd_scan_lowrank_split<GATE, 2, false, 4>); }
+    else               { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, 4>); else go(fwd_scan_lowrank_split<GATE, 0, false, 4>); }
+    return;
+  }
   if (aux == 1)      { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true>); else go(fwd_scan_lowrank_split<GATE, 1, false>); }
   else if (aux == 2) { if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true>); else go(fwd_scan_lowrank_split<GATE, 2, false>); }
   else               { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true>); else go(fwd_scan_lowrank_split<GATE, 0, false>); }
