@@ -1284,8 +1284,8 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
 // the factors.
 constexpr int SLAB_LR = 576;   // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded to 64
 
-template <int GATE, bool RAGGED>
-__global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
+template <int GATE, bool RAGGED, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ hs, const float* __restrict__ pre_s,
     const float* __restrict__ h0, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ u1, const float* __restrict__ u2,
@@ -1293,10 +1293,12 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ d_x, float* __restrict__ d_h0,
     float* __restrict__ dpre_ws, float* __restrict__ dm_ws, float* __restrict__ part) {
-  constexpr int H = 256, F = 32, R = 16, NT = 4, MROW = 36;
-  __shared__ __attribute__((aligned(16))) float mp[2][4][16][MROW];
+  // NW waves (8 = two per SIMD, 32 units each; 4 = the first shape): see fwd_scan_lowrank_split
+  constexpr int H = 256, F = 32, R = 16, UPW = H / NW, NT = UPW / 16, KU = UPW / 32, UPL = UPW / 4, MROW = 36;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
   __shared__ __attribute__((aligned(16))) float sbias[2][H];
-  __shared__ float red[8];
+  __shared__ float red[2 * NW];
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1304,18 +1306,18 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
   const int b = blockIdx.x * 16 + i;
   const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
-  const int n0 = wv * 64 + g * 16;
+  const int n0 = wv * UPW + g * UPL;
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
-  sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid];
+  if (tid < H) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
 
   // ---- resident A operands -----------------------------------------------------------------
   // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units: tile 0 rows = U2 columns, tile 1 = W2 columns
-  Frag3 UW2Tf[2][2];
+  Frag3 UW2Tf[2][KU];
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     const float* src = tl == 0 ? u2 : w2;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < KU; ++v) {
       f32x4 lo, hi;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1329,7 +1331,7 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
   Frag3 U1Tf[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {
-    const int kA = wv * 64 + (i >> 2) * 16 + mt * 4 + (i & 3);
+    const int kA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
     f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
     if (g < 2) {
 #pragma unroll
@@ -1374,7 +1376,17 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
 
   auto step = [&](int t, const EwOps& e, EwOps& e_load) __attribute__((always_inline)) {
     const int cur = t & 1;
+    {
+      // dh read = the previous step's MFMAs have retired: the requests below may land in registers they read
+      // (operand rule)
+      float touch = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
+      if (touch == 1.2345678e38f) red[0] = 1.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (t > 0) load_ew(t - 1, e_load);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
     f32x4 dpv[NT];
 #pragma unroll
@@ -1402,17 +1414,20 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
       for (int mt = 0; mt < NT; ++mt) st4(o + 4 * mt, dpv[mt]);
     }
     // ---- rank-space partial over own units: B operand = this lane's two fragments of d_pre ----
-    const Frag3 d0 = split3(dpv[0], dpv[1]), d1 = split3(dpv[2], dpv[3]);
-    f32x4 mh = mfma6(UW2Tf[0][0], d0, f32x4{0.f, 0.f, 0.f, 0.f});
-    mh = mfma6(UW2Tf[0][1], d1, mh);
-    f32x4 mx = mfma6(UW2Tf[1][0], d0, f32x4{0.f, 0.f, 0.f, 0.f});
-    mx = mfma6(UW2Tf[1][1], d1, mx);
+    Frag3 dfr[KU];
+#pragma unroll
+    for (int v = 0; v < KU; ++v) dfr[v] = split3(dpv[2 * v], dpv[2 * v + 1]);
+    f32x4 mh = f32x4{0.f, 0.f, 0.f, 0.f}, mx = mh;
+#pragma unroll
+    for (int v = 0; v < KU; ++v) mh = mfma6(UW2Tf[0][v], dfr[v], mh);
+#pragma unroll
+    for (int v = 0; v < KU; ++v) mx = mfma6(UW2Tf[1][v], dfr[v], mx);
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
     lds_barrier();
     f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
 #pragma unroll
-    for (int w2i = 0; w2i < 4; ++w2i) {
+    for (int w2i = 0; w2i < NW; ++w2i) {
       mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
       mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
     }
@@ -1424,8 +1439,10 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
     // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) dh[mt] = mfma6(U1Tf[mt], mB, dh[mt]);
-    const f32x4 dxv = mfma6(W1Tf, mB, f32x4{0.f, 0.f, 0.f, 0.f});
-    if (wv < 2 && valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, dxv);
+    if (wv < 2) {                                    // (wave-uniform) feature tile wv
+      const f32x4 dxv = mfma6(W1Tf, mB, f32x4{0.f, 0.f, 0.f, 0.f});
+      if (valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, dxv);
+    }
   };
 
   EwOps ea, eb;
@@ -1457,12 +1474,14 @@ __global__ __launch_bounds__(256) void bwd_scan_lowrank_split(
     }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
-  if (l == 0) { red[wv] = pz; red[4 + wv] = pn; }
+  if (l == 0) { red[wv] = pz; red[NW + wv] = pn; }
   __syncthreads();
   if (tid == 0) {
     float* pzn = part + (size_t)blockIdx.x * SLAB_LR + 2 * H;
-    pzn[0] = red[0] + red[1] + red[2] + red[3];
-    pzn[1] = red[4] + red[5] + red[6] + red[7];
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int w2i = 0; w2i < NW; ++w2i) { a += red[w2i]; c += red[NW + w2i]; }
+    pzn[0] = a; pzn[1] = c;
   }
 }
 
@@ -1686,13 +1705,15 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   float* splitk = (float*)(base + L.splitk);
   const int nwg = (d.B + 15) / 16;
   const size_t TB = (size_t)d.T * d.B;
-  auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, s, d.T, d.B, (const float*)ghs, (const float*)hs,
+  auto go = [&](auto kern, int threads) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), 0, s, d.T, d.B, (const float*)ghs, (const float*)hs,
                        (const float*)pre_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
                        (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, dpre, dm, part);
   };
-  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true>); else go(bwd_scan_lowrank_split<GATE, false>);
+  // full batches: 8 waves (two per SIMD); ragged ones stay on the 4-wave shape (the 8-wave ragged variant needs
+  // more than its 256 registers, and spill reloads break the operand rule)
+  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, 4>, 256); else go(bwd_scan_lowrank_split<GATE, false, 8>, 512);
   hipLaunchKernelGGL(reduce_lowrank_small, dim3((2 * 256 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
                      (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
                      (float*)g.d_nu);
