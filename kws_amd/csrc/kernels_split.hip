@@ -698,6 +698,11 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
     constexpr bool FIRST = decltype(first_tag)::value;
     // ---- A: rank-space partials ------------------------------------------------------------
     const Frag3 xB = split3(xuse.lo, xuse.hi);
+    // xB is needed inside a wave-uniform branch only; left alone the compiler sinks the split AND the load of
+    // x_0 into that branch, i.e. behind the MFMAs below and into their dead operand registers (the first step
+    // of the 4-wave variant came out wrong that way).  The empty asm pins the planes here (operand rule, 4.0).
+    asm volatile("" :: "v"(xB.p[0]), "v"(xB.p[1]), "v"(xB.p[2]));
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});                      // rnn.py:286 (partial over own units)
     if constexpr (KU == 2) mh = mfma6(U1f[1], hfrag[1], mh);
     f32x4 mx = f32x4{0.f, 0.f, 0.f, 0.f};                                               // m_x enters the sum once:

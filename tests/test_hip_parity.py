@@ -943,3 +943,24 @@ def test_model_tail_last_state_plus_head_matches_the_reference_chain():
         scale = max(1e-12, float(g_ref[n].abs().max()))
         assert float((p_.grad - g_ref[n]).abs().max()) / scale <= 2e-5, n
     assert float((x2.grad - x1.grad).abs().max()) / max(1e-12, float(x1.grad.abs().max())) <= 2e-5
+
+
+@pytest.mark.parametrize("B", [32, 21])
+def test_lowrank_forward_wave_shapes_agree(B):
+    """The low-rank forward runs 8 waves of 32 units (default) or 4 waves of 64 (FLAG_FWD_4WAVE, the first shape,
+    kept for A/B): same arithmetic per element, different order of the eight / four rank-space partial sums, so
+    hs, the pre-activation and the rank-space vector agree to fp32 rounding."""
+    T, F, H, r = 15, 32, 256, 16
+    p = O.make_params(F, H, r, r, seed=51, randomize_scalars=True)
+    P = _param_tensors(p)
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(T, B, F, generator=g).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    args = (x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])
+    for base in (0, 4):
+        a = fastgrnn_cuda.forward_unroll(*args, flags=base)
+        b = fastgrnn_cuda.forward_unroll(*args, flags=base | 8)
+        assert len(a) == len(b)
+        for k, (u_, v_) in enumerate(zip(a, b)):
+            scale = max(1.0, float(u_.abs().max()))
+            assert float((u_ - v_).abs().max()) / scale <= 2e-5, (base, k)

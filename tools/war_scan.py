@@ -62,8 +62,8 @@ for name, ins in kernels.items():
         done = regs(ops[0], "va")                # results of this and of later MFMAs: reading one means this one retired
         for j in range(i + 1, min(i + 1 + N, len(ins))):
             m = ins[j]
-            if m.startswith("s_cbranch") or m.startswith("s_branch"):
-                break
+            if m.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                break                            # (a conditional branch falls through: keep scanning that path)
             if m.startswith("v_mfma"):
                 done |= regs(m.split(None, 1)[1].split(",")[0], "va")
                 continue
