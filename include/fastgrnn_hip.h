@@ -103,7 +103,8 @@ typedef enum fastgrnn_nonlinearity {
  *   GRAD_LAST  backward_unroll: grad_hs is [B,H], the gradient of the last state; every other step's is zero and
  *              is neither materialised nor read (a dense zero [T,B,H] is what autograd would otherwise write and the
  *              kernel read: 2 x 208 MB at B=4096).  hs, the saved tensors and every output keep their shapes.
- *   HS_LAST    forward_unroll (inference: z_s must be NULL): hs is [B,H] and receives h_T only.
+ *   HS_LAST    forward_unroll (inference: z_s must be NULL): hs is [B,H] and receives h_T only (a separately
+ *              compiled kernel variant: equal to the last row of the full forward to fp32 rounding).
  * Both: dense H=128/F=32 (8-wave kernels), any sequence layout; FASTGRNN_ERR_UNSUPPORTED otherwise. */
 #define FASTGRNN_FLAG_GRAD_LAST 256u
 #define FASTGRNN_FLAG_HS_LAST 512u

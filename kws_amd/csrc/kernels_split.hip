@@ -440,8 +440,10 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
   const int n0 = wv * 16 + g * 4;                  // this lane's 4 hidden units
-  // mode bit 0: x is the trainer's [B,F,T]; bit 1 (FASTGRNN_FLAG_HS_LAST, AUX == 0 only): hs is [B,H], h_T alone
-  const bool xbft = (mode & 1) != 0, hs_last = AUX == 0 && (mode & 2) != 0;
+  // mode bit 0: x is the trainer's [B,F,T].  AUX == 3 (FASTGRNN_FLAG_HS_LAST): hs is [B,H] and receives h_T alone
+  // (a compile-time variant: as a run-time test in store_step it cost the plain AUX == 0 forward 8 %)
+  const bool xbft = (mode & 1) != 0;
+  constexpr bool hs_last = AUX == 3;
   // feature element this lane converts each step: utterance xu, feature xf
   const int xu = tid >> 5, xf = tid & 31;
   const int xb = blockIdx.x * 16 + xu;
@@ -1753,10 +1755,15 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   };
   auto go8 = [&](auto kern) __attribute__((always_inline)) {     // 8-wave kernels also take the x layout
     hipLaunchKernelGGL(kern, grid, dim3(512), 0, s, d.T, d.B, row_stride_t(d), row_stride_b(d),
-                       ((d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0) | ((d.flags & FASTGRNN_FLAG_HS_LAST) ? 2 : 0), (const float*)x, (const float*)h0, (const float*)p.w,
+                       (d.flags & FASTGRNN_FLAG_X_BFT) ? 1 : 0, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  if (d.flags & FASTGRNN_FLAG_HS_LAST) {             // inference: h_T alone (split_supported() admits aux == 0 only)
+    if (d.dtype == FASTGRNN_BF16_IO) { if (ragged) go8(fwd_scan_split_w8<GATE, 3, true, true>); else go8(fwd_scan_split_w8<GATE, 3, false, true>); }
+    else                             { if (ragged) go8(fwd_scan_split_w8<GATE, 3, true>); else go8(fwd_scan_split_w8<GATE, 3, false>); }
+    return;
+  }
   if (d.dtype == FASTGRNN_BF16_IO) {                 // bf16 sequences: 8-wave kernel, hs only or hs + pre-activation
     block = dim3(512);
     if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, true>); else go8(fwd_scan_split_w8<GATE, 2, false, true>); }
