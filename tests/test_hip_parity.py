@@ -884,7 +884,8 @@ def test_module_last_state_matches_indexing_the_sequence(kind):
         assert inf.shape == last.shape and float((inf.float() - last.detach().float()).abs().max()) <= tol
 
 
-@pytest.mark.parametrize("B,H,Cn", [(64, 128, 12), (37, 128, 12), (4096, 128, 12), (50, 256, 35), (1, 64, 2), (130, 20, 64)])
+@pytest.mark.parametrize("B,H,Cn", [(64, 128, 12), (37, 128, 12), (4096, 128, 12), (50, 256, 35), (1, 64, 2), (130, 20, 64),
+                                    (33, 256, 64)])      # the last one needs 86 KB of dynamic LDS (opt-in attribute)
 def test_classifier_head_loss_and_gradients_vs_torch_cpu(B, H, Cn):
     """fastgrnn_hip_head_xent == NLLLoss()(log_softmax(Linear(h)), y) and its autograd gradients, computed by
     torch on the CPU in float64 (model.py:226-230, trainClassifier.py:154,236) and by the numpy oracle
