@@ -630,6 +630,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
   constexpr int MROW = 36;   // padded floats per (wave, utterance) row of m
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
+  __shared__ __attribute__((aligned(16))) float msum[2][16][MROW];   // NW == 8: the summed rank-space vector
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -720,10 +721,24 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
     __builtin_amdgcn_sched_barrier(0);
     // ---- m = sum of the partials; this lane's B fragment is rows 8g..8g+7 of [m_h ; m_x] -------
     f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
+    if constexpr (NW == 8) {
+      // Two stages: every wave needs the whole sum, and eight waves each reading all eight partials is 131 KB of
+      // LDS reads per step.  512 threads = 16 utterances x 32 values: each adds ONE value's eight partials (same
+      // order as below: identical bits), the sums go through a 2 KB buffer and one more barrier.
+      const int u = tid & 15, j = tid >> 4;
+      float sj = 0.f;
 #pragma unroll
-    for (int w2i = 0; w2i < NW; ++w2i) {
-      mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
-      mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
+      for (int w2i = 0; w2i < NW; ++w2i) sj += mp[cur][w2i][u][j];
+      msum[cur][u][j] = sj;
+      lds_barrier();
+      mlo = *reinterpret_cast<const f32x4*>(&msum[cur][i][8 * g]);
+      mhi = *reinterpret_cast<const f32x4*>(&msum[cur][i][8 * g + 4]);
+    } else {
+#pragma unroll
+      for (int w2i = 0; w2i < NW; ++w2i) {
+        mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
+        mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
+      }
     }
     if (AUX == 2) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
     const Frag3 mB = split3(mlo, mhi);
@@ -1433,6 +1448,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
     lds_barrier();
     f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
+    // (the forward's two-stage sum was tried here too: 1 % at most, and its extra registers made the kernel spill)
 #pragma unroll
     for (int w2i = 0; w2i < NW; ++w2i) {
       mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
