@@ -97,8 +97,6 @@ typedef enum fastgrnn_nonlinearity {
 /* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
  * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
 #define FASTGRNN_FLAG_FWD_BF16X3 64u
-/* Retired: selected an older 4-wave backward kernel; accepted and ignored (the 8-wave backward always runs). */
-#define FASTGRNN_FLAG_BWD_4WAVE 32u
 /* SURVEY 8(f) N2 -- the classifier's view of the LAST layer (model.py:227 reads hs[T-1] alone):
  *   GRAD_LAST  backward_unroll: grad_hs is [B,H], the gradient of the last state; every other step's is zero and
  *              is neither materialised nor read (a dense zero [T,B,H] is what autograd would otherwise write and the
@@ -196,7 +194,9 @@ int fastgrnn_hip_backward(const fastgrnn_desc *d, const fastgrnn_params *p,
  *   keyword_scores = F.log_softmax(self.hidden2keyword(hs[T-1]), dim=1)     (model.py:86-88, 226-230)
  *   loss = nn.NLLLoss()(keyword_scores, labels)                              (trainClassifier.py:154,236; mean)
  * and their backward.  fp32.  h_last:[B,H] (e.g. the FASTGRNN_FLAG_HS_LAST / last_state output), fc_w:[C,H],
- * fc_b:[C] (nn.Linear layout), labels:[B] int64 in [0,C).  Writes loss[1], log_probs:[B,C] (may be NULL),
+ * fc_b:[C] (nn.Linear layout), labels:[B] int64 in [0,C) or -100 (nn.NLLLoss's default ignore_index: such rows add
+ * neither loss nor gradient and the mean runs over the others; any other out-of-range label makes the loss NaN,
+ * where torch raises a device-side assert).  Writes loss[1], log_probs:[B,C] (may be NULL),
  * d_h_last:[B,H] = dLoss/dh_last, d_fc_w:[C,H], d_fc_b:[C] (overwritten).  Deterministic (fixed-order reduction).
  * H <= 256, C <= 64, else FASTGRNN_ERR_UNSUPPORTED.  workspace: fastgrnn_hip_head_workspace_bytes(B,H,C). */
 size_t fastgrnn_hip_head_workspace_bytes(int32_t B, int32_t H, int32_t C);

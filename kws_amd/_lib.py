@@ -21,7 +21,6 @@ FLAG_FORCE_F32_MFMA = 2
 FLAG_SAVE_PREACT = 4
 FLAG_FWD_4WAVE = 8            # A/B: older 4-wave forward shape
 FLAG_FWD_BF16X3 = 64          # A/B: forward state product on three bf16 planes
-FLAG_BWD_4WAVE = 32           # retired (accepted and ignored): the 4-wave backward is gone
 FLAG_X_BFT = 128              # x / d_x are the trainer's [B,F,T]
 FLAG_GRAD_LAST = 256          # backward_unroll: grad_h is [B,H], the gradient of the last state alone (model.py:227)
 FLAG_HS_LAST = 512            # forward_unroll (inference, no saved tensors): hs is [B,H] = h_T

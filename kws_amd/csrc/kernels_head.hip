@@ -15,11 +15,12 @@ namespace {
 constexpr int HEAD_UTT = 16;        // utterances per workgroup (B = 4096 -> 256 workgroups, one per CU)
 constexpr int HEAD_THREADS = 256;
 constexpr int HEAD_MAX_C = 64, HEAD_MAX_H = 256;
+constexpr long long HEAD_IGNORE_INDEX = -100;   // torch.nn.NLLLoss default
 
 // dynamic LDS: hT[HEAD_UTT][H+1] | W[C][H+1] | dl[HEAD_UTT][C+1]
 __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
     int B, int H, int C, const float* __restrict__ h_last, const float* __restrict__ fc_w,
-    const float* __restrict__ fc_b, const long long* __restrict__ labels, float inv_B,
+    const float* __restrict__ fc_b, const long long* __restrict__ labels,
     float* __restrict__ logp, float* __restrict__ d_h, float* __restrict__ part) {
   extern __shared__ float lds[];
   const int HP = H + 1, CP = C + 1;
@@ -30,6 +31,24 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * HEAD_UTT;
   const int nu = min(HEAD_UTT, B - b0);
+
+  // nn.NLLLoss() semantics (trainClassifier.py:154: default reduction 'mean', ignore_index = -100): rows whose
+  // label is -100 contribute neither loss nor gradient and the mean runs over the other rows.  Every workgroup
+  // counts them itself (B labels from L2, fixed order: deterministic).  Any other label outside [0,C) is an
+  // error in torch (device-side assert); here it makes the loss NaN instead of silently dropping the row.
+  __shared__ int s_cnt[HEAD_THREADS / 64];
+  {
+    int cnt = 0;
+    for (int e = tid; e < B; e += HEAD_THREADS) cnt += (labels[e] != HEAD_IGNORE_INDEX) ? 1 : 0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  }
+  __syncthreads();
+  int n_rows = 0;
+#pragma unroll
+  for (int k = 0; k < HEAD_THREADS / 64; ++k) n_rows += s_cnt[k];
+  const float inv_B = n_rows > 0 ? 1.0f / (float)n_rows : __builtin_nanf("");   // torch: mean over zero rows is NaN
 
   // ---- stage the tile of h_T (coalesced rows) and the weights
   for (int e = tid; e < HEAD_UTT * H; e += HEAD_THREADS) {
@@ -63,11 +82,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
     float l = 0.f;
     if (u < nu) {
       const long long y = labels[b0 + u];
+      const bool ignored = y == HEAD_IGNORE_INDEX;
+      if (!ignored && (y < 0 || y >= C)) l = __builtin_nanf("");      // invalid label: loud, not dropped
       for (int c = 0; c < C; ++c) {
         const float lp = row[c] - lse;
         if (logp) logp[(size_t)(b0 + u) * C + c] = lp;
         if (c == (int)y) l = -lp;                                       // trainClassifier.py:236
-        row[c] = (expf(lp) - (c == (int)y ? 1.f : 0.f)) * inv_B;
+        row[c] = ignored ? 0.f : (expf(lp) - (c == (int)y ? 1.f : 0.f)) * inv_B;
       }
     } else {
       for (int c = 0; c < C; ++c) row[c] = 0.f;
@@ -146,15 +167,14 @@ int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const v
               void* loss, void* logp, void* d_h, void* d_w, void* d_b, void* ws, hipStream_t s) {
   const int nwg = (B + HEAD_UTT - 1) / HEAD_UTT;
   const size_t lds = head_lds_bytes(H, C);
-  static bool attr_done = false;                   // > 64 KB of dynamic LDS needs the opt-in once per process
-  if (!attr_done) {
+  // > 64 KB of dynamic LDS needs the opt-in; the attribute is per device, so it is set before every launch
+  // that needs it (no process-wide state: the library is re-entrant and device-agnostic)
+  if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_xent_fwd_bwd),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(head_xent_fwd_bwd, dim3(nwg), dim3(HEAD_THREADS), lds, s, B, H, C, (const float*)h_last,
-                     (const float*)fc_w, (const float*)fc_b, (const long long*)labels, 1.0f / (float)B, (float*)logp,
+                     (const float*)fc_w, (const float*)fc_b, (const long long*)labels, (float*)logp,
                      (float*)d_h, part);
   const int n = C * H + C + 1;
   hipLaunchKernelGGL(head_reduce, dim3((n + 31) / 32), dim3(256), 0, s, nwg, n, C * H, C, (const float*)part,

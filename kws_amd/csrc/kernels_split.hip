@@ -62,9 +62,10 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 
 // bf16 I/O variant (FASTGRNN_BF16_IO): sequences x / hs / grad_hs / d_x are bf16 in HBM, everything else fp32
 __device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
-__device__ __forceinline__ unsigned f32_to_bf16_rne(float f) {          // round to nearest even (finite inputs)
-  const unsigned u = __builtin_bit_cast(unsigned, f);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+// round to nearest even on the hardware converter (v_cvt_pk_bf16_f32): a NaN stays a NaN (the integer form
+// (u + 0x7FFF + lsb) >> 16 turns some NaNs into 0 / inf -- MI355X_MICROARCH.md, correctness boundaries)
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float f) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ f32x4 ld4_bf16(const void* p) {               // 4 consecutive bf16 -> 4 floats
   const uint2 v = *reinterpret_cast<const uint2*>(p);
@@ -72,8 +73,11 @@ __device__ __forceinline__ f32x4 ld4_bf16(const void* p) {               // 4 co
                __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
 }
 __device__ __forceinline__ void st4_bf16(void* p, const f32x4 v) {
-  *reinterpret_cast<uint2*>(p) = uint2{f32_to_bf16_rne(v[0]) | (f32_to_bf16_rne(v[1]) << 16),
-                                       f32_to_bf16_rne(v[2]) | (f32_to_bf16_rne(v[3]) << 16)};
+  typedef __bf16 bf16x2_cv __attribute__((ext_vector_type(2)));
+  typedef float f32x2_cv __attribute__((ext_vector_type(2)));
+  const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{v[0], v[1]}, bf16x2_cv));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{v[2], v[3]}, bf16x2_cv));
+  *reinterpret_cast<uint2*>(p) = uint2{lo, hi};
 }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -122,7 +126,7 @@ __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __b
 // instruction).  Rounding, not truncating, matters: truncated planes all carry the sign of v, so the three
 // dropped cross terms (p1.q2 + p2.q1 + p2.q2) pushed every product toward zero by ~4e-8 relative -- harmless
 // per product, but one-signed, and it showed in the two scalar gradients that sum a million terms (d_zeta,
-// d_nu: 3e-4 relative against 1e-5 for the fp32 paths; tests/dev/bias_probe.py).  With rounded planes the
+// d_nu: 3e-4 relative against 1e-5 for the fp32 paths).  With rounded planes the
 // dropped terms are zero-mean and below 2^-26.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -449,11 +453,36 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   const int xb = blockIdx.x * 16 + xu;
   const int xbc = (!RAGGED || xb < B) ? xb : B - 1;
 
-  // F16H: the state product U.h_{t-1} runs on fp16 two-plane operands (3 MFMAs per K-step instead of 6, two
-  // state planes through LDS instead of three).  h is bounded (|h| <= max(|h0|, sigma(zeta)+sigma(nu))), so
-  // its planes are always in fp16's range; U is pre-scaled per wave by an exact power of two that puts its
-  // largest element in [2^12, 2^13) (lo planes stay normal), undone by one fma in the epilogue.  W.x keeps
-  // the three bf16 planes: x is unbounded user data.  Measured error vs fp64 is that of an fp32 matmul.
+  const f32x4 bzv = ld4(bz + n0), bhv = ld4(bh + n0);
+  f32x4 hown = ld4(h0 + (size_t)bc * H + n0);
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+
+  // F16H: the state product U.h_{t-1} MAY run on fp16 two-plane operands (3 MFMAs per K-step instead of 6, two
+  // state planes through LDS instead of three).  That needs |h| inside fp16's range for the whole scan.  The
+  // host only instantiates F16H for gates with z in [0,1] (sigmoid, quantSigm, quantSigm4; a relu or tanh gate
+  // does not bound h at all).  For those,  |h_t| <= z|h_{t-1}| + sigma(zeta)(1-z) + sigma(nu)
+  //                                              <= max(|h_{t-1}|, sigma(zeta)) + sigma(nu),
+  // i.e. |h_t| <= max(|h0|, 1) + t: the workgroup checks its own 16 rows of h0 against that bound here and
+  // falls back to the three-bf16-plane product (no range limit) when a user-supplied h0 is too large (or NaN).
+  // Two planes resolve 2^-22 of the value anywhere in range (lo subnormal below 2^-14: absolute 2^-24), and U is
+  // pre-scaled per wave by an exact power of two that puts its largest element in [2^12, 2^13), undone by one
+  // fma in the epilogue.  W.x keeps the three bf16 planes: x is unbounded user data.
+  bool use_h16 = false;
+  if constexpr (F16H) {
+    __shared__ float hmax_s[8];
+    float hm = fmaxf(fmaxf(fabsf(hown[0]), fabsf(hown[1])), fmaxf(fabsf(hown[2]), fabsf(hown[3])));
+    if (!(hm == hm)) hm = 3.0e38f;                  // NaN in h0: take the path without a range assumption
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) hm = fmaxf(hm, __shfl_xor(hm, m));
+    if (l == 0) hmax_s[wv] = hm;
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) hm = fmaxf(hm, hmax_s[k2]);
+    use_h16 = __builtin_amdgcn_readfirstlane((int)(hm + (float)Tn + 2.0f < 3.0e4f)) != 0;
+  }
+
+  auto scan = [&](auto h16_tag) __attribute__((always_inline)) {
+  constexpr bool H16 = decltype(h16_tag)::value;
   Frag3 Uf[KS], Wf;
   Frag2h Uh[KS];
   float u_unscale = 1.0f;
@@ -468,7 +497,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
 #pragma unroll
       for (int j = 0; j < 4; ++j) umax = fmaxf(umax, fmaxf(fabsf(ulo[s2][j]), fabsf(uhi[s2][j])));
     }
-    if (F16H) {
+    if (H16) {
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) umax = fmaxf(umax, __shfl_xor(umax, m));
       int e = 0;
@@ -485,14 +514,11 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     const float* wp = w + (size_t)nA * F + 8 * g;
     Wf = split3(ld4(wp), ld4(wp + 4));
   }
-  const f32x4 bzv = ld4(bz + n0), bhv = ld4(bh + n0);
-  f32x4 hown = ld4(h0 + (size_t)bc * H + n0);
-  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
 
   // planes of this lane's 4 state values -> 8 bytes per plane at [utterance i][unit n0]
   auto publish_h = [&](int buf) __attribute__((always_inline)) {
     const unsigned off = i * W8_ROWH + n0 * 2;
-    if (F16H) {
+    if (H16) {
       uint2 hi, lo;
       split2h(hown[0], hown[1], hi.x, lo.x); split2h(hown[2], hown[3], hi.y, lo.y);
       *reinterpret_cast<uint2*>(&hpl[buf][0][off]) = hi;
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(&xpl[cur][p][i * W8_ROWX + 16 * g]);
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
-      if (F16H) {
+      if (H16) {
         hH[s2].hi = *reinterpret_cast<const u32x4*>(&hpl[cur][0][i * W8_ROWH + 64 * s2 + 16 * g]);
         hH[s2].lo = *reinterpret_cast<const u32x4*>(&hpl[cur][1][i * W8_ROWH + 64 * s2 + 16 * g]);
       } else {
@@ -570,7 +596,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     // big and small terms in accumulators of their own (see mfma6_hl), summed once at the end
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, alo = a;
     mfma6_hl(Wf, xB, a, alo);
-    if (F16H) {
+    if (H16) {
       f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f}, ahlo = ah;
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) mfma3h_hl(Uh[s2], hH[s2], ah, ahlo);               // .cu:368, scaled by 2^k
@@ -603,6 +629,12 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
 #endif
   store_step(Tn - 1, aux_prev);
+  };
+  if constexpr (F16H) {
+    if (use_h16) scan(std::true_type{}); else scan(std::false_type{});
+  } else {
+    scan(std::false_type{});
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -955,11 +987,18 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     const bool g_zero = g_last && t != Tn - 1;       // wave-uniform
     if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
       e.graw = g_zero ? uint2{0u, 0u} : *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + og);
+      if (RAGGED && !valid) e.graw = uint2{0u, 0u};
       e.hraw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(hs) + (t == 0 ? o : o - (size_t)rsT * H));
+      // h_prev of step 0 is the fp32 h0: requested HERE, with the step's other operands (load_ew runs behind a
+      // completion read), not in unpack_ew, which sits between the chain's MFMAs and the first read of their result
+      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);
       e.xraw = reinterpret_cast<const unsigned short*>(x)[ex];
     } else {
       const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
       e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(ghs + og);
+      // Lanes beyond a ragged batch re-read the last utterance's (finite) rows with a ZERO gradient: with dh = 0
+      // at the start, gg, d_pre and every sum they enter stay exactly zero for them -- nothing else to mask.
+      if (RAGGED && !valid) e.g = f32x4{0.f, 0.f, 0.f, 0.f};
       e.h = ld4(hprev);
       e.xv = x[ex];
     }
@@ -972,8 +1011,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   auto unpack_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
     if (BF) {
       e.g = unpack4(e.graw);
-      e.h = unpack4(e.hraw);
-      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);   // once per launch
+      if (t != 0) e.h = unpack4(e.hraw);                 // (t == 0: load_ew fetched the fp32 h0)
       e.xv = bf16_to_f32(e.xraw);
     }
   };
@@ -993,9 +1031,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       } else {
         z = e.a0[r]; c = e.a1[r];
       }
-      float kc = (sz * (1.0f - z) + sn) * (1.0f - c * c);       // d_pre_c = kc * gg   (.cu:109)
-      float kz = (e.h[r] - sz * c) * gate_dact<GATE>(z);        // d_pre_z = kz * gg   (.cu:110)
-      if (RAGGED && !valid) { kc = 0.f; kz = 0.f; z = 0.f; c = 0.f; }
+      const float kc = (sz * (1.0f - z) + sn) * (1.0f - c * c); // d_pre_c = kc * gg   (.cu:109)
+      const float kz = (e.h[r] - sz * c) * gate_dact<GATE>(z);  // d_pre_z = kz * gg   (.cu:110)
       f.kc[r] = kc; f.kz[r] = kz; f.z[r] = z; f.c[r] = c;
     }
   };
@@ -1023,9 +1060,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     }
     unsigned char* im = &S.img[t & 3][0];
     put4(im + OFF_DP, PLANE_H, my_row_h, dpv);
-    f32x4 hv = e.h;
-    if (RAGGED && !valid) hv = f32x4{0.f, 0.f, 0.f, 0.f};
-    put4(im + OFF_HP, PLANE_H, my_row_h, hv);
+    put4(im + OFF_HP, PLANE_H, my_row_h, e.h);
     {
       unsigned short s0, s1, s2;
       split_one(e.xv, s0, s1, s2);
@@ -1121,13 +1156,21 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     EwPre f;
     auto chain = [&]() __attribute__((always_inline)) {
       // d_h chain (.cu:537), C-in = z*g; d_x partial of step t (.cu:538) from the same fragments
-      f32x4 dlo = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 dlo = z4;
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) mfma6_hl(UTf[s2], dB[s2], dh, dlo);
       dh += dlo;
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2)                // (a runtime index would put the fragments in scratch)
-        if (xks == s2) S.DX[t & 1][wv][l] = mfma6(WTf, dB[s2], f32x4{0.f, 0.f, 0.f, 0.f});
+      // (a runtime index would put the fragments in scratch.)  Every arm issues the product -- the last one
+      // unconditionally: xks < KS -- and the partial is stored OUTSIDE the selection: that store is the read which
+      // proves these MFMAs, the youngest of the step, have retired (tools/war_scan.py follows every feasible path).
+      f32x4 dxp;
+      static_assert(KS == 4, "four K-steps");
+      if (xks == 0) dxp = mfma6(WTf, dB[0], z4);
+      else if (xks == 1) dxp = mfma6(WTf, dB[1], z4);
+      else if (xks == 2) dxp = mfma6(WTf, dB[2], z4);
+      else dxp = mfma6(WTf, dB[3], z4);
+      S.DX[t & 1][wv][l] = dxp;
     };
     // Same order in both waves of a SIMD.  (Measured, tools/mfma_share_probe.hip: two waves with MFMAs ready
     // do not interleave on the matrix pipe -- one streams at 16.7 cycles per MFMA, the other waits -- and a
@@ -1280,7 +1323,6 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, part);
   };
-  // FASTGRNN_FLAG_BWD_4WAVE is accepted and ignored: the 4-wave backward it used to select is retired
   if (d.dtype == FASTGRNN_BF16_IO) {
     if (ragged) go8(bwd_scan_split_w8<GATE, true, true, true>); else go8(bwd_scan_split_w8<GATE, true, false, true>);
   } else if (preact) {
@@ -1385,14 +1427,21 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   float pz = 0.f, pn = 0.f;
 
   struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
+  // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
+  // of a 64-bit pointer pair each (the host rejects B*H*4 >= 2^31 for this path).
+  const unsigned lane_h = (unsigned)bc * H + n0, lane_hs = (unsigned)b * H + n0;
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t o = ((size_t)t * B + bc) * H + n0;
-    const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)B * H;   // .cu:478-481
+    const size_t step = (size_t)t * B * H;                                   // uniform
+    const float* gt = ghs + step;
+    const float* pt = pre_s + step;
+    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)B * H);          // .cu:478-481
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-      e.g[mt] = ld4(ghs + o + 4 * mt);
-      e.a0[mt] = ld4(pre_s + o + 4 * mt);
-      e.h[mt] = ld4(hprev + 4 * mt);
+      // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero, so gg,
+      // d_pre and every sum they enter stay exactly zero for them; see bwd_scan_split_w8)
+      e.g[mt] = (RAGGED && !valid) ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(gt + lane_h + 4 * mt);
+      e.a0[mt] = ld4(pt + lane_h + 4 * mt);
+      e.h[mt] = ld4(ht + lane_h + 4 * mt);
     }
   };
 
@@ -1420,18 +1469,17 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
         const float z = gate_act<GATE>(e.a0[mt][r] + bzq[r]);
         const float c = ftanh(e.a0[mt][r] + bhq[r]);
         const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
-        float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;                // .cu:109
-        float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;             // .cu:110
-        float zg = z * gg;                                                        // .cu:108
-        float tz = (1.0f - z) * c * gg, tn = c * gg;                              // .cu:114-115
-        if (RAGGED && !valid) { dcp = 0.f; dzp = 0.f; zg = 0.f; tz = 0.f; tn = 0.f; }
+        const float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;          // .cu:109
+        const float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;       // .cu:110
+        const float zg = z * gg;                                                  // .cu:108
+        const float tz = (1.0f - z) * c * gg, tn = c * gg;                        // .cu:114-115
         sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
         dpv[mt][r] = dzp + dcp;                                                   // .cu:113
         dh[mt][r] = zg;
       }
     }
     if (valid) {
-      float* o = dpre_ws + ((size_t)t * B + b) * H + n0;
+      float* o = dpre_ws + (size_t)t * B * H + lane_hs;
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt) st4(o + 4 * mt, dpv[mt]);
     }
@@ -1455,7 +1503,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
     }
     if (wv == 0 && valid) {                          // [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
-      float* mo = dm_ws + ((size_t)t * B + b) * 32 + 8 * g;
+      float* mo = dm_ws + (size_t)t * B * 32 + ((unsigned)b * 32 + 8 * g);
       st4(mo, mlo); st4(mo + 4, mhi);
     }
     const Frag3 mB = split3(mlo, mhi);
@@ -1464,7 +1512,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     for (int mt = 0; mt < NT; ++mt) dh[mt] = mfma6(U1Tf[mt], mB, dh[mt]);
     if (wv < 2) {                                    // (wave-uniform) feature tile wv
       const f32x4 dxv = mfma6(W1Tf, mB, f32x4{0.f, 0.f, 0.f, 0.f});
-      if (valid) st4(d_x + ((size_t)t * B + b) * F + wv * 16 + 4 * g, dxv);
+      if (valid) st4(d_x + (size_t)t * B * F + ((unsigned)b * F + wv * 16 + 4 * g), dxv);
+      // these are the step's youngest MFMAs: an unconditional read of their result (the store above is skipped
+      // by lanes beyond a ragged batch) before the next step's requests may reuse their operand registers
+      if (RAGGED && dxv[0] == 1.2345678e38f) red[1] = 1.f;
     }
   };
 
@@ -1477,6 +1528,15 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     step(t - 1, eb, ea);
   }
   if (t == 0) step(0, ea, eb);
+  {
+    // the last step's MFMAs have retired before anything below (stores masked by `valid`, the reductions' LDS
+    // traffic) may reuse their operand registers: an unconditional read of every d_h accumulator
+    float touch = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
+    if (touch == 1.2345678e38f) red[0] = 1.f;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // ---- flush ---------------------------------------------------------------------------------
   if (valid) {
 #pragma unroll
@@ -1736,7 +1796,7 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   };
   // full batches: 8 waves (two per SIMD); ragged ones stay on the 4-wave shape (the 8-wave ragged variant needs
   // more than its 256 registers, and spill reloads break the operand rule)
-  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, 4>, 256); else go(bwd_scan_lowrank_split<GATE, false, 8>, 512);
+  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, 8>, 512); else go(bwd_scan_lowrank_split<GATE, false, 8>, 512);
   hipLaunchKernelGGL(reduce_lowrank_small, dim3((2 * 256 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
                      (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
                      (float*)g.d_nu);
@@ -1775,29 +1835,37 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs);
   };
+  // fp16 two-plane state product (F16H) only for gates that keep z in [0,1] -- they bound the growth of h to
+  // sigma(nu) per step, and the kernel itself checks h0 (see fwd_scan_split_w8); relu / tanh / quantTanh gates
+  // always run the three-bf16-plane product, as does FASTGRNN_FLAG_FWD_BF16X3 (A/B)
+  constexpr bool BOUNDED = GATE == FASTGRNN_NL_SIGMOID || GATE == FASTGRNN_NL_QUANT_SIGM || GATE == FASTGRNN_NL_QUANT_SIGM4;
+  const bool h16 = BOUNDED && !(d.flags & FASTGRNN_FLAG_FWD_BF16X3);
+  const bool bf = d.dtype == FASTGRNN_BF16_IO;
+  auto pick8 = [&](auto aux_tag) __attribute__((always_inline)) {
+    constexpr int A = decltype(aux_tag)::value;
+    if constexpr (BOUNDED) {
+      if (h16) {
+        if (bf) { if (ragged) go8(fwd_scan_split_w8<GATE, A, true, true, true>); else go8(fwd_scan_split_w8<GATE, A, false, true, true>); }
+        else    { if (ragged) go8(fwd_scan_split_w8<GATE, A, true, false, true>); else go8(fwd_scan_split_w8<GATE, A, false, false, true>); }
+        return;
+      }
+    }
+    if (bf) { if (ragged) go8(fwd_scan_split_w8<GATE, A, true, true, false>); else go8(fwd_scan_split_w8<GATE, A, false, true, false>); }
+    else    { if (ragged) go8(fwd_scan_split_w8<GATE, A, true, false, false>); else go8(fwd_scan_split_w8<GATE, A, false, false, false>); }
+  };
   if (d.flags & FASTGRNN_FLAG_HS_LAST) {             // inference: h_T alone (split_supported() admits aux == 0 only)
-    if (d.dtype == FASTGRNN_BF16_IO) { if (ragged) go8(fwd_scan_split_w8<GATE, 3, true, true>); else go8(fwd_scan_split_w8<GATE, 3, false, true>); }
-    else                             { if (ragged) go8(fwd_scan_split_w8<GATE, 3, true>); else go8(fwd_scan_split_w8<GATE, 3, false>); }
+    pick8(std::integral_constant<int, 3>{});
     return;
   }
-  if (d.dtype == FASTGRNN_BF16_IO) {                 // bf16 sequences: 8-wave kernel, hs only or hs + pre-activation
-    block = dim3(512);
-    if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, true>); else go8(fwd_scan_split_w8<GATE, 2, false, true>); }
-    else          { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, true>); else go8(fwd_scan_split_w8<GATE, 0, false, true>); }
+  if (bf) {                                          // bf16 sequences: hs only or hs + pre-activation
+    if (aux == 2) pick8(std::integral_constant<int, 2>{}); else pick8(std::integral_constant<int, 0>{});
     return;
   }
-  if ((d.flags & FASTGRNN_FLAG_FWD_BF16X3) && (GATE > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST)) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE))) {   // A/B: state product on 3 bf16 planes
-    block = dim3(512);
-    if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true, false, false>); else go8(fwd_scan_split_w8<GATE, 1, false, false, false>); }
-    else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true, false, false>); else go8(fwd_scan_split_w8<GATE, 2, false, false, false>); }
-    else               { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true, false, false>); else go8(fwd_scan_split_w8<GATE, 0, false, false, false>); }
-    return;
-  }
-  if (GATE > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST)) || !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {   // default: the 8-wave shape
-    block = dim3(512);
-    if (aux == 1)      { if (ragged) go8(fwd_scan_split_w8<GATE, 1, true>); else go8(fwd_scan_split_w8<GATE, 1, false>); }
-    else if (aux == 2) { if (ragged) go8(fwd_scan_split_w8<GATE, 2, true>); else go8(fwd_scan_split_w8<GATE, 2, false>); }
-    else               { if (ragged) go8(fwd_scan_split_w8<GATE, 0, true>); else go8(fwd_scan_split_w8<GATE, 0, false>); }
+  if (GATE > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST | FASTGRNN_FLAG_FWD_BF16X3)) ||
+      !(d.flags & FASTGRNN_FLAG_FWD_4WAVE)) {        // default: the 8-wave shape
+    if (aux == 1)      pick8(std::integral_constant<int, 1>{});
+    else if (aux == 2) pick8(std::integral_constant<int, 2>{});
+    else               pick8(std::integral_constant<int, 0>{});
     return;
   }
   if constexpr (GATE <= FASTGRNN_NL_TANH) {          // the 4-wave kernel knows the reference's three gates only
@@ -1832,7 +1900,8 @@ void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
 }
 
 bool lowrank_fwd_shape(const fastgrnn_desc& d) {
-  return d.H == 256 && d.F == 32 && d.w_rank == 16 && d.u_rank == 16;
+  // B < 2^21: the scans address a step's rows with 32-bit lane offsets (B*H*4 bytes < 2^31)
+  return d.H == 256 && d.F == 32 && d.w_rank == 16 && d.u_rank == 16 && d.B < (1 << 21);
 }
 
 }  // namespace

@@ -60,11 +60,10 @@ def _check_grads(g, ref, tol, tag):
     for k, v in ref.items():
         scale = max(1.0, float(np.abs(v).max()))
         err = float(np.abs(g[k].reshape(v.shape) - v).max()) / scale
-        # d_zeta / d_nu are ONE scalar each: a sum of T*B*H random-sign terms, i.e. |sum| is
-        # ~sqrt(N) times smaller than the sum of magnitudes and an fp32 accumulation (the
-        # reference's included) is only good to ~sqrt(N) * 6e-8 relative to it
-        lim = max(tol, 5e-5) if (k in ("d_zeta", "d_nu") and g[k].dtype != np.float64) else tol
-        assert err <= lim, (tag, k, err)
+        # (d_zeta / d_nu -- ONE scalar each, a sum of T*B*H random-sign terms -- used to get 5e-5 here; since the
+        # rounded plane split and the separate small-term accumulator they meet the common limit, also at the
+        # BASELINE sizes: tests/test_hip_fullsize.py)
+        assert err <= tol, (tag, k, err)
 
 
 @pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
@@ -425,7 +424,7 @@ def test_full_size_backward_linearity_and_shard_sum():
     g2 = _bwd(2.0 * G, x, hs, zs, cs, P, h0)
     for a, b in zip(g1, g2):
         if a.numel():
-            assert (2.0 * a - b).abs().max() <= 1e-4 * max(1.0, float(b.abs().max()))
+            assert (2.0 * a - b).abs().max() <= 2e-6 * max(1.0, float(b.abs().max()))   # scaling by 2 is exact in every plane
     half = B // 2
     parts = []
     for sl in (slice(0, half), slice(half, B)):
@@ -434,17 +433,19 @@ def test_full_size_backward_linearity_and_shard_sum():
         parts.append(_bwd(Gs, xs, hs_s, zs_s, cs_s, P, hz))
     for i in (1, 2, 3, 4, 6, 7):   # d_bias_z, d_bias_h, d_zeta, d_nu, d_w, d_u
         s = parts[0][i] + parts[1][i]
-        # the two scalars are sums of 5e7 random-sign terms: different (equally valid) fp32
-        # summation orders differ by ~sqrt(N)*6e-8 of the sum of magnitudes
-        tol = 2e-3 if i in (3, 4) else 2e-5
-        assert (s - g1[i]).abs().max() <= tol * max(1.0, float(g1[i].abs().max())), i
+        # each side is within 2e-5 of the fp64 oracle (tests/test_hip_fullsize.py): two valid fp32 summation
+        # orders may differ by twice that
+        assert (s - g1[i]).abs().max() <= 4e-5 * max(1.0, float(g1[i].abs().max())), i
     assert torch.allclose(torch.cat([parts[0][0], parts[1][0]], 1), g1[0], atol=1e-6, rtol=0)
-    # against the generic path
+    # the generic path AND the dispatched one against the fp64 oracle on the whole batch
     gg = _bwd(G, x, hs, zs, cs, P, h0, flags=FORCE_GENERIC)
-    for i, (a, b) in enumerate(zip(g1, gg)):
-        if a.numel():
-            tol = 2e-3 if i in (3, 4) else 2e-5
-            assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())), i
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64, G64 = x.cpu().numpy().astype(np.float64), G.cpu().numpy().astype(np.float64)
+    hs_o, zs_o, cs_o = O.unroll_forward(x64, p64)
+    g_o = O.unroll_backward(G64, x64, hs_o, zs_o, cs_o, p64)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+    for tag, got in (("dispatch", g1), ("generic", gg)):
+        _check_grads({n: o.cpu().numpy() for n, o in zip(names, got[:8])}, g_o, 2e-5, tag)
 
 
 def test_lowrank_config4_shape_vs_oracle_sample():
@@ -756,10 +757,9 @@ def test_module_takes_the_trainers_permuted_view():
 def test_ab_kernel_variants_agree_with_the_default(B):
     """The A/B flags select an older kernel shape / operand format of the same arithmetic: 4-wave forward (8),
     three-bf16-plane forward state product (64).  They must agree with the default kernels to fp32 rounding
-    (they differ in summation order and, for 64, in the operand split).  32 (the retired 4-wave backward) is
-    accepted and ignored."""
+    (they differ in summation order and, for 64, in the operand split)."""
     T, F, H = 40, 32, 128
-    SAVE_PREACT, FWD_4WAVE, BWD_4WAVE, FWD_BF16X3 = 4, 8, 32, 64
+    SAVE_PREACT, FWD_4WAVE, FWD_BF16X3 = 4, 8, 64
     p = O.make_params(F, H, seed=12, randomize_scalars=True)
     P = _param_tensors(p)
     g = torch.Generator().manual_seed(14)
@@ -776,11 +776,11 @@ def test_ab_kernel_variants_agree_with_the_default(B):
         return list(outs) + list(gr[:8])
 
     ref = run(SAVE_PREACT)
-    for extra in (FWD_4WAVE, FWD_BF16X3, FWD_4WAVE | FWD_BF16X3, BWD_4WAVE, FWD_4WAVE | BWD_4WAVE):
+    for extra in (FWD_4WAVE, FWD_BF16X3, FWD_4WAVE | FWD_BF16X3):
         got = run(SAVE_PREACT | extra)
         for k, (a, b) in enumerate(zip(ref, got)):
             scale = max(1.0, float(a.abs().max()))
-            tol = 1e-4 if k in (5, 6) else 2e-5           # d_zeta, d_nu: scalar sums over T*B*H terms
+            tol = 4e-5 if k in (5, 6) else 2e-5           # d_zeta, d_nu: two valid summation orders, each within 2e-5
             assert float((a - b).abs().max()) / scale <= tol, (extra, k)
 
 

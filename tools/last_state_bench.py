@@ -2,7 +2,7 @@
 Module path, B=4096 T=99 F=32 H=128: hs[-1].backward(g) against forward(..., last_state=True).backward(g), and
 the inference forward with / without the hidden-state sequence."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kws_amd.rnn import FastGRNNCUDA
 
