@@ -69,7 +69,7 @@ int fastgrnn_hip_kernel_path(const fastgrnn_desc* d, int direction) {
 size_t fastgrnn_hip_forward_workspace_bytes(const fastgrnn_desc* d) {
   if (check_desc(d) != FASTGRNN_OK) return 0;
   switch (pick_path(d, 0)) {
-    case 2: return 0;
+    case 2: return split_forward_ws(*d);
     case 1: return mfma_forward_ws(*d);
     default: return generic_forward_ws(*d);
   }
@@ -95,7 +95,9 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
        d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 0) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if ((d->flags & FASTGRNN_FLAG_HS_LAST) && z_s) return FASTGRNN_ERR_UNSUPPORTED;   // nothing is saved for a backward
-  if ((st = check_ws(workspace, workspace_bytes, fastgrnn_hip_forward_workspace_bytes(d)))) return st;
+  // (path 2 only needs its workspace when no auxiliary output is requested: see split_forward_ws)
+  const size_t need = (pick_path(d, 0) == 2 && z_s && !h256_shape(*d)) ? 0 : fastgrnn_hip_forward_workspace_bytes(d);
+  if ((st = check_ws(workspace, workspace_bytes, need))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (pick_path(d, 0)) {
     case 2: return split_forward(*d, *p, x, h0, hs, z_s, c_s, workspace, s);

@@ -69,12 +69,35 @@ int mfma_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
 
 // split-precision (3 x bf16 planes, 6 MFMA terms) scan on the bf16 matrix pipe (kernels_split.hip)
 bool split_supported(const fastgrnn_desc& d, int direction);
+size_t split_forward_ws(const fastgrnn_desc& d);
 size_t split_backward_ws(const fastgrnn_desc& d);
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
                   void* hs, void* zs, void* cs, void* ws, hipStream_t s);
 int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
                    const void* hs, const void* zs, const void* cs, const void* h0,
                    const fastgrnn_grads& g, void* ws, hipStream_t s);
+
+// batched split-precision GEMMs around the scans (kernels_gemm.hip)
+//   rows_gemm:   C[R,N] = A[R,K] . Wt^T, Wt[n][k] = trans_w ? W[k*N + n] : W[n*K + k]; A / C may be bf16 sequences
+//   tn_gemm_big: C[M,N] (row stride ldc) = A[R,M]^T . B[R,N]; rows of B below shiftB come from B0, the rest from B1
+//                shifted down by shiftB rows; part: tn_gemm_big_ws(R, M, N) bytes
+bool rows_gemm_supported(int N, int K, bool trans_w);
+int rows_gemm(size_t R, int N, int K, bool trans_w, const void* A, const float* W, void* C, bool bf_in, bool bf_out,
+              hipStream_t s);
+bool tn_gemm_big_supported(int M, int N);
+size_t tn_gemm_big_ws(size_t R, int M, int N);
+int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t shiftB,
+                    int ldb, float* part, float* C, int ldc, hipStream_t s);
+
+// dense H = 256 / F = 32 scans (kernels_h256.hip), dispatched through split_supported / split_forward / split_backward
+bool h256_shape(const fastgrnn_desc& d);
+bool h256_supported(const fastgrnn_desc& d, int direction);
+size_t h256_forward_ws(const fastgrnn_desc& d);
+size_t h256_backward_ws(const fastgrnn_desc& d);
+int h256_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
+                 void* cs, void* ws, hipStream_t s);
+int h256_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                  const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
 
 // classifier head on the last state: Linear + log_softmax + NLL, forward and backward (kernels_head.hip)
 bool head_supported(int B, int H, int C);

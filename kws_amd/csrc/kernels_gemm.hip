@@ -1,0 +1,398 @@
+// Batched split-precision GEMMs around the scans (gfx950): the genuinely dense, non-recurrent contractions of a
+// FastGRNN layer whose input or hidden width is too large for the register-resident scans of kernels_split.hip
+// (the reference's default stack 32 -> 256 -> 128, trainingConfig.py:12-15; model.py:196-203).
+//
+//   rows_gemm_split   C[R,N] = A[R,K] . Wt[N,K]^T     R = T*B rows, (N,K) small: the frame GEMM  X . W^T  in front of
+//                     the recurrence (.cu:356,368 evaluates it per step) and  d_x = d_pre . W  behind it (.cu:538)
+//   tn_gemm_big       C[M,N] = A[R,M]^T . B[R,N]       the weight gradients  dW = d_pre^T X,  dU = d_pre^T H_prev
+//                     (.cu:539-540 accumulates them per step) for M, N up to 256
+//
+// Same arithmetic as the scans: every fp32 operand is split exactly into three bf16 planes, six MFMA terms per
+// product on v_mfma_f32_16x16x32_bf16, fp32 accumulation, big and small terms in separate accumulators; results
+// are fp32 tensors with fp32-level accuracy.  Both kernels are written to the operand rule of DESIGN.md 4.0
+// (fragment reads before the first MFMA of a batch, completion reads before registers are reused) and are
+// checked by tools/war_scan.py.
+#include "split_common.h"
+
+namespace fastgrnn {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// C[R,N] = A[R,K] . Wt[N,K]^T
+// ------------------------------------------------------------------------------------------
+// Workgroup = 8 waves, persistent over a contiguous range of 32-row stages.  The weights are the MFMA A operand
+// (rows = output columns n), resident in registers as planes for the whole launch: wave (wn, wr) owns NPW
+// n-tiles and every WR-th 16-row tile of a stage.  A stage of A is loaded with coalesced 16-byte reads, split
+// ONCE per workgroup, and published as natural [row][k] plane images (double-buffered); the waves read their B
+// fragments (columns = rows of A) from there with conflict-free ds_read_b128.
+//   TRANS_W: Wt[n][k] = W[k * N + n] (the caller's matrix is [K,N]: d_x = d_pre . W with W:[H,F]).
+//   BF_IN / BF_OUT: A / C are bf16 (FASTGRNN_BF16_IO sequences); arithmetic and W stay fp32.
+constexpr int RG_ROWS = 32;                       // rows per stage (two MFMA column tiles)
+
+template <int NT, int KS, bool TRANS_W, bool BF_IN = false, bool BF_OUT = false>
+__global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_wg, const void* __restrict__ Av,
+                                                       const float* __restrict__ W, void* __restrict__ Cv) {
+  constexpr int K = 32 * KS, N = 16 * NT;
+  constexpr int WN = NT >= 8 ? 8 : NT, WR = 8 / WN, NPW = NT / WN, RT = RG_ROWS / 16;
+  constexpr int ROWB = K * 2 + 16;                // bytes per row of a plane image (+16: conflict-free b128 reads)
+  constexpr int VPT = RG_ROWS * K / 4 / 512;      // float4 per thread per stage
+  constexpr int KB = KS < 4 ? KS : 4;             // K-steps per fragment batch
+  static_assert(NT % WN == 0 && VPT >= 1 && KS % KB == 0, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned char pl[2][3][RG_ROWS * ROWB];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int wn = wv % WN, wr = wv / WN;
+
+  // ---- resident weights: planes of Wt rows n = 16 * (wn * NPW + a) + i, K in natural order ------------------
+  Frag3 Wf[NPW][KS];
+#pragma unroll
+  for (int a = 0; a < NPW; ++a) {
+    const int n = 16 * (wn * NPW + a) + i;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4 lo, hi;
+      if (TRANS_W) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[j] = W[(size_t)(32 * s + 8 * g + j) * N + n];
+          hi[j] = W[(size_t)(32 * s + 8 * g + 4 + j) * N + n];
+        }
+      } else {
+        const float* wp = W + (size_t)n * K + 32 * s + 8 * g;
+        lo = ld4(wp); hi = ld4(wp + 4);
+      }
+      Wf[a][s] = split3(lo, hi);
+    }
+  }
+
+  const size_t nstages = (R + RG_ROWS - 1) / RG_ROWS;
+  const size_t s_begin = (size_t)blockIdx.x * stages_per_wg;
+  const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
+  if (s_begin >= s_end) return;                   // (whole workgroup: no barrier has been passed)
+
+  f32x4 va[VPT];
+  uint2 vraw[VPT];                                // bf16 input: four values per 8 bytes, unpacked at publish time
+  auto load_stage = [&](size_t st) __attribute__((always_inline)) {
+    const size_t r0 = st * RG_ROWS;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int idx = tid + 512 * j, row = idx / (K / 4);
+      const size_t e = r0 * K + (size_t)idx * 4;  // rows are contiguous: element offset of this thread's four values
+      const bool ok = r0 + row < R;
+      if (BF_IN) vraw[j] = ok ? *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(Av) + e) : uint2{0u, 0u};
+      else va[j] = ok ? ld4(reinterpret_cast<const float*>(Av) + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto publish = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int idx = tid + 512 * j, row = idx / (K / 4), c4 = idx % (K / 4);
+      f32x4 v;
+      if (BF_IN) v = f32x4{bitsf(vraw[j].x << 16), bitsf(vraw[j].x & 0xFFFF0000u), bitsf(vraw[j].y << 16), bitsf(vraw[j].y & 0xFFFF0000u)};
+      else v = va[j];
+      uint2 q0, q1, q2;
+      split_quad(v, q0, q1, q2);
+      const unsigned off = (unsigned)(row * ROWB + c4 * 8);
+      *reinterpret_cast<uint2*>(&pl[buf][0][off]) = q0;
+      *reinterpret_cast<uint2*>(&pl[buf][1][off]) = q1;
+      *reinterpret_cast<uint2*>(&pl[buf][2][off]) = q2;
+    }
+  };
+
+  load_stage(s_begin);
+  publish(0);
+  __syncthreads();
+  if (s_begin + 1 < s_end) load_stage(s_begin + 1);
+
+  int buf = 0;
+  for (size_t st = s_begin; st < s_end; ++st, buf ^= 1) {
+    const size_t r0 = st * RG_ROWS;
+    // ---- this wave's tiles of the stage ----------------------------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (WR > 1 && (rt % WR) != wr) continue;     // (wave-uniform) with fewer than eight n-tiles the r-tiles are dealt out
+      const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 hi[NPW], lo[NPW];
+#pragma unroll
+      for (int a = 0; a < NPW; ++a) { hi[a] = z4; lo[a] = z4; }
+#pragma unroll
+      for (int k0 = 0; k0 < KS; k0 += KB) {
+        // all fragment reads of the batch are issued, each into registers of its own, before its first MFMA
+        Frag3 Bf[KB];
+#pragma unroll
+        for (int s = 0; s < KB; ++s)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            Bf[s].p[p] = *reinterpret_cast<const u32x4*>(&pl[buf][p][(rt * 16 + i) * ROWB + (32 * (k0 + s) + 8 * g) * 2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KB; ++s)
+#pragma unroll
+          for (int a = 0; a < NPW; ++a) mfma6_hl(Wf[a][k0 + s], Bf[s], hi[a], lo[a]);
+        __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks MFMAs below the read)
+        float touch = 0.f;                         // every accumulator of the batch has retired before Bf is reloaded
+#pragma unroll
+        for (int a = 0; a < NPW; ++a) touch += hi[a][0] + lo[a][0];
+        if (touch == 1.2345678e38f) pl[0][0][0] = 1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const size_t r = r0 + rt * 16 + i;
+      if (r < R) {
+#pragma unroll
+        for (int a = 0; a < NPW; ++a) {
+          const f32x4 o = hi[a] + lo[a];
+          const size_t e = r * N + 16 * (wn * NPW + a) + 4 * g;
+          if (BF_OUT) st4_bf16(reinterpret_cast<unsigned short*>(Cv) + e, o);
+          else st4(reinterpret_cast<float*>(Cv) + e, o);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- next stage: planes into the other buffer, then the request for the stage after it -----------------
+    if (st + 1 < s_end) publish(buf ^ 1);
+    lds_barrier();
+    if (st + 2 < s_end) load_stage(st + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {                                               // the weight fragments stay allocated through the last stage
+    float probe = 0.f;
+#pragma unroll
+    for (int a = 0; a < NPW; ++a)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) keep_alive(probe, Wf[a][s]);
+  }
+}
+
+template <int NT, int KS, bool TRANS_W>
+void launch_rows_gemm(size_t R, const void* A, const float* W, void* C, bool bf_in, bool bf_out, hipStream_t s) {
+  const size_t nstages = (R + RG_ROWS - 1) / RG_ROWS;
+  const int nwg = (int)(nstages < 256 ? nstages : 256);                  // one workgroup per CU (LDS: 50-100 KB)
+  const int spw = (int)((nstages + nwg - 1) / nwg);
+  if (bf_in && bf_out) hipLaunchKernelGGL((rows_gemm_split<NT, KS, TRANS_W, true, true>), dim3(nwg), dim3(512), 0, s, R, spw, A, W, C);
+  else if (bf_in) hipLaunchKernelGGL((rows_gemm_split<NT, KS, TRANS_W, true, false>), dim3(nwg), dim3(512), 0, s, R, spw, A, W, C);
+  else if (bf_out) hipLaunchKernelGGL((rows_gemm_split<NT, KS, TRANS_W, false, true>), dim3(nwg), dim3(512), 0, s, R, spw, A, W, C);
+  else hipLaunchKernelGGL((rows_gemm_split<NT, KS, TRANS_W, false, false>), dim3(nwg), dim3(512), 0, s, R, spw, A, W, C);
+}
+
+// ------------------------------------------------------------------------------------------
+// C[M,N] = A[R,M]^T . B[R,N]   (M = 128 per workgroup row block, N = 16 * NT <= 256)
+// ------------------------------------------------------------------------------------------
+// Workgroup = 8 waves = one chunk of rows x one 128-column block of A (grid.y).  Stages of 32 rows (one MFMA
+// K-step): global fp32 -> three exact bf16 planes in LDS in natural [row][column] order (double-buffered, the
+// next stage's loads in flight under the MFMAs) -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs
+// into register accumulators.  Wave w owns m-tiles 2(w&3), 2(w&3)+1 of the block and n-tiles (w>>2)*NT/2 ...:
+// two A fragments for the stage, B fragments in batches of four.  Each workgroup leaves its partial C in the
+// workspace; tn_big_reduce sums them in a fixed order (deterministic, no atomics).
+// Rows of B below shiftB come from B0 (h0: H_prev of step 0), the rest from B1 shifted down by shiftB rows.
+constexpr int TNB_STAGE = 32;
+
+template <int NT>
+__global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, const float* __restrict__ A, int lda,
+                                                   const float* __restrict__ B0, const float* __restrict__ B1,
+                                                   size_t shiftB, int ldb, float* __restrict__ part) {
+  constexpr int MB = 128, N = 16 * NT, NH = NT / 2, NBATCH = NH < 4 ? NH : 4;
+  constexpr int ROWA = MB * 2 + 32, ROWB = N * 2 + 32;
+  constexpr int VA = TNB_STAGE * MB / 4 / 512, VB = (TNB_STAGE * N / 4 + 511) / 512;   // float4 per thread per stage
+  static_assert(NT % 2 == 0 && NH % NBATCH == 0 && VA >= 1, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned char la[2][3][TNB_STAGE * ROWA];
+  __shared__ __attribute__((aligned(16))) unsigned char lb[2][3][TNB_STAGE * ROWB];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+  const int mq = wv & 3, nh = wv >> 2;
+  const int mblk = blockIdx.y;                     // 128-column block of A
+  const size_t nstages = (R + TNB_STAGE - 1) / TNB_STAGE;
+  const size_t s_begin = (size_t)blockIdx.x * stages_per_wg;
+  const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
+
+  f32x4 va[VA], vb[VB];
+  auto load_stage = [&](size_t st) __attribute__((always_inline)) {
+    const size_t r0 = st * TNB_STAGE;
+#pragma unroll
+    for (int j = 0; j < VA; ++j) {
+      const int idx = tid + 512 * j, row = idx / (MB / 4), c4 = idx % (MB / 4);
+      const size_t r = r0 + row;
+      va[j] = r < R ? ld4(A + r * lda + mblk * MB + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+      const int idx = tid + 512 * j, row = idx / (N / 4), c4 = idx % (N / 4);
+      const size_t r = r0 + row;
+      const float* src = r < shiftB ? B0 + r * (size_t)ldb : B1 + (r - shiftB) * (size_t)ldb;   // H_prev: rows of t = 0 are h0
+      vb[j] = (idx < TNB_STAGE * N / 4 && r < R) ? ld4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto put = [&](unsigned char* p0, int plane_bytes, unsigned off, const f32x4 v) __attribute__((always_inline)) {
+    uint2 q0, q1, q2;
+    split_quad(v, q0, q1, q2);
+    *reinterpret_cast<uint2*>(p0 + off) = q0;
+    *reinterpret_cast<uint2*>(p0 + plane_bytes + off) = q1;
+    *reinterpret_cast<uint2*>(p0 + 2 * plane_bytes + off) = q2;
+  };
+  auto publish = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < VA; ++j) {
+      const int idx = tid + 512 * j, row = idx / (MB / 4), c4 = idx % (MB / 4);
+      put(&la[buf][0][0], TNB_STAGE * ROWA, (unsigned)(row * ROWA + c4 * 8), va[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+      const int idx = tid + 512 * j, row = idx / (N / 4), c4 = idx % (N / 4);
+      if (idx < TNB_STAGE * N / 4) put(&lb[buf][0][0], TNB_STAGE * ROWB, (unsigned)(row * ROWB + c4 * 8), vb[j]);
+    }
+  };
+
+  f32x4 acc[2][NH];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < NH; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    const unsigned la0 = (unsigned)(size_t)&la[0][0][0], lb0 = (unsigned)(size_t)&lb[0][0][0];
+    // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
+    const unsigned trA = la0 + (8 * g + q) * ROWA + (mq * 32 + 4 * pp) * 2;
+    const unsigned trB = lb0 + (8 * g + q) * ROWB + (nh * NH * 16 + 4 * pp) * 2;
+    load_stage(s_begin);
+    publish(0);
+    __syncthreads();
+    if (s_begin + 1 < s_end) load_stage(s_begin + 1);
+    int buf = 0;
+    for (size_t st = s_begin; st < s_end; ++st, buf ^= 1) {
+      const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * 3 * TNB_STAGE * ROWB;
+      Frag3 Af[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) Af[a].p[p] = tr_frag(trA + oa + p * (TNB_STAGE * ROWA) + a * 32, ROWA);
+#pragma unroll
+      for (int c0 = 0; c0 < NH; c0 += NBATCH) {
+        Frag3 Bf[NBATCH];
+#pragma unroll
+        for (int c = 0; c < NBATCH; ++c)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) Bf[c].p[p] = tr_frag(trB + ob + p * (TNB_STAGE * ROWB) + (c0 + c) * 32, ROWB);
+        __builtin_amdgcn_sched_barrier(0);        // every fragment read of the batch is issued before its first MFMA
+#pragma unroll
+        for (int c = 0; c < NBATCH; ++c)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) acc[a][c0 + c] = mfma6(Af[a], Bf[c], acc[a][c0 + c]);
+        __builtin_amdgcn_sched_barrier(0);
+        float touch = 0.f;                         // all of the batch's MFMAs have retired before Bf / Af are reloaded
+#pragma unroll
+        for (int c = 0; c < NBATCH; ++c) touch += acc[0][c0 + c][0] + acc[1][c0 + c][0];
+        if (touch == 1.2345678e38f) part[0] = 1.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (st + 1 < s_end) publish(buf ^ 1);
+      lds_barrier();
+      if (st + 2 < s_end) load_stage(st + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D row 4g + r of tile (mt, nt) is m = 16 mt + 4g + r, column n = 16 nt + (l & 15)
+  float* pc = part + ((size_t)blockIdx.x * gridDim.y + mblk) * MB * N;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < NH; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pc[(size_t)(mq * 32 + a * 16 + 4 * g + r) * N + (nh * NH + c) * 16 + (l & 15)] = acc[a][c][r];
+}
+
+// C[(mblk*128 + m) * ldc + n] = sum over row chunks of part[chunk][mblk][m][n], fixed order
+__global__ __launch_bounds__(1024) void tn_big_reduce(int nchunk, int nblk, int N, const float* __restrict__ part,
+                                                      float* __restrict__ C, int ldc) {
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
+  const int per_blk = 128 * N, total = nblk * per_blk;
+  const int idx = blockIdx.x * 64 + o;
+  float a = 0.f;
+  if (idx < total) {
+    const int blk = idx / per_blk, e = idx - blk * per_blk;
+    for (int c0 = pid; c0 < nchunk; c0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 16 * j;
+        v[j] = c < nchunk ? part[((size_t)c * nblk + blk) * per_blk + e] : 0.f;
+      }
+      a += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  sm[pid][o] = a;
+  __syncthreads();
+  if (pid == 0 && idx < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    const int blk = idx / per_blk, e = idx - blk * per_blk, m = e / N, n = e - m * N;
+    C[(size_t)(blk * 128 + m) * ldc + n] = t;
+  }
+}
+
+}  // namespace
+
+// ---- launchers (declared in common.h) -------------------------------------------------------------------------
+bool rows_gemm_supported(int N, int K, bool trans_w) {
+  // N * K <= 128 * 256: the weight planes of a wave's tiles (N * K * 12 / 512 registers per lane) fit beside the
+  // fragments; N = 256 with K = 256 would spill (and spill reloads are loads: operand rule)
+  const bool k_ok = K == 64 || K == 128 || K == 256;
+  if (!k_ok || N * K > 128 * 256) return false;
+  if (!trans_w) return N == 128 || N == 256;
+  return N == 32 || N == 64 || N == 128 || N == 256;
+}
+
+int rows_gemm(size_t R, int N, int K, bool trans_w, const void* A, const float* W, void* C, bool bf_in, bool bf_out,
+              hipStream_t s) {
+#define RG_CASE(n, k)                                                                     \
+  if (N == n && K == k) {                                                                 \
+    if (trans_w) launch_rows_gemm<n / 16, k / 32, true>(R, A, W, C, bf_in, bf_out, s);    \
+    else launch_rows_gemm<n / 16, k / 32, false>(R, A, W, C, bf_in, bf_out, s);           \
+    return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;           \
+  }
+  if (!rows_gemm_supported(N, K, trans_w)) return FASTGRNN_ERR_UNSUPPORTED;
+  RG_CASE(128, 64) RG_CASE(128, 128) RG_CASE(128, 256)
+  RG_CASE(256, 64) RG_CASE(256, 128)
+  RG_CASE(32, 64) RG_CASE(32, 128) RG_CASE(32, 256) RG_CASE(64, 64) RG_CASE(64, 128) RG_CASE(64, 256)
+#undef RG_CASE
+  return FASTGRNN_ERR_UNSUPPORTED;
+}
+
+static inline int tnb_chunks(size_t R, int nblk, int* spw) {
+  const size_t nstages = (R + TNB_STAGE - 1) / TNB_STAGE;
+  size_t want = 256 / (size_t)nblk;                // one workgroup per CU over the whole grid
+  if (want < 1) want = 1;
+  if (want > nstages) want = nstages;
+  *spw = (int)((nstages + want - 1) / want);
+  return (int)((nstages + *spw - 1) / *spw);
+}
+
+bool tn_gemm_big_supported(int M, int N) { return (M == 128 || M == 256) && (N == 32 || N == 64 || N == 128 || N == 256); }
+
+size_t tn_gemm_big_ws(size_t R, int M, int N) {
+  int spw;
+  const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
+  return align256((size_t)nch * nblk * 128 * N * sizeof(float));
+}
+
+int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t shiftB,
+                    int ldb, float* part, float* C, int ldc, hipStream_t s) {
+  if (!tn_gemm_big_supported(M, N)) return FASTGRNN_ERR_UNSUPPORTED;
+  int spw;
+  const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
+  dim3 grid(nch, nblk);
+#define TNB_CASE(n) \
+  if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, A, lda, B0, B1, shiftB, ldb, part);
+  TNB_CASE(32) TNB_CASE(64) TNB_CASE(128) TNB_CASE(256)
+#undef TNB_CASE
+  const int total = M * N;
+  hipLaunchKernelGGL(tn_big_reduce, dim3((total + 63) / 64), dim3(1024), 0, s, nch, nblk, N, (const float*)part, C, ldc);
+  return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
+}
+
+}  // namespace fastgrnn

@@ -1,0 +1,728 @@
+// Split-precision FastGRNN scans for the dense H = 256, F = 32 layer (gfx950): the first layer of the reference's
+// default stack (trainingConfig.py:12-15: 32 -> 256 -> 128; model.py:196-203).
+//
+// Same arithmetic, geometry and rules as the H = 128 scans of kernels_split.hip -- fp32 operands as exact bf16 /
+// fp16 planes on v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulation, one workgroup of 8 waves = 16 utterances for all
+// T, the operand rule of DESIGN.md 4.0 -- but U is 4x larger: 256 KB as fp32, more than the register file of a CU
+// can hold as three bf16 planes next to anything else.  What is resident where:
+//   forward, bounded state (gate with z in [0,1] and a bounded h0, checked on the device):  U as TWO fp16 planes in
+//       registers (128 per lane), the state product costs 3 MFMAs per K-step;
+//   forward otherwise:  bf16 planes 0 and 1 of U in registers, plane 2 in LDS in fragment order (128 KB: each wave
+//       re-reads only its own fragments, 16 ds_read_b128 per step, so the LDS acts as a second register file); six
+//       MFMA terms per K-step as everywhere else;
+//   backward:  U^T as two fp16 planes, hi in registers (64 per lane), lo in LDS; d_pre as two fp16 planes scaled by
+//       an exact power of two per (utterance, 32-unit slice) -- see bwd_scan_h256.
+// Wave w owns hidden units 32w..32w+31 (two 16-row tiles, eight K-steps).  W (32 wide) stays fused in the forward as
+// in the H = 128 kernel.  The backward keeps the recurrence only and writes d_pre[T,B,H]: dU, dW and d_x are batched
+// GEMMs afterwards (kernels_gemm.hip; .cu:538-540 does them per step) -- neither U^T's planes nor the 256 KB of dU
+// accumulators would fit on chip beside each other.
+// Reference semantics: forward .cu:42-60 + .cu:367-413; backward .cu:91-119 + .cu:473-545.
+#include "split_common.h"
+
+namespace fastgrnn {
+namespace {
+
+constexpr int H2 = 256, F2 = 32, KS2 = 8;
+constexpr int ROWH2 = 528;                      // bytes per utterance row of a 256-wide 16-bit plane (512 + 16)
+constexpr int ROWX2 = 80;                       // ... of a 32-wide plane (64 + 16)
+constexpr int PLH2 = 16 * ROWH2;                // 8448: one state plane
+constexpr int PLX2 = 16 * ROWX2;                // 1280
+constexpr int U2L = 8 * 2 * KS2 * 64 * 16;      // 131072: plane 2 of every wave's weight fragments
+constexpr int SLAB2 = 576;                      // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// AUX: 0 = hs only; 1 = also z_s, h_prime_s (the reference operator's outputs); 2 = also the pre-activation
+// W.x + U.h into zs (FASTGRNN_FLAG_SAVE_PREACT); 3 = hs is [B,H] and receives h_T alone (FASTGRNN_FLAG_HS_LAST).
+// MODE 0: bf16 path, unconditionally.  MODE 1: fp16 path for the workgroups whose rows of h0 allow it; the others
+// set their word of `flags` and leave at once.  MODE 2: bf16 path for exactly those workgroups (launched right behind
+// MODE 1 on the same stream; a workgroup whose flag is clear leaves at once).  Two kernels instead of one with both
+// paths inside: together they needed a dozen registers more than a wave has, i.e. spill reloads inside the loop.
+template <int GATE, int AUX, bool RAGGED, int MODE>
+__global__ __launch_bounds__(512) void fwd_scan_h256(
+    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    const float* __restrict__ w, const float* __restrict__ u,
+    const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags) {
+  constexpr bool F16H = MODE == 1;
+  if (MODE == 2 && flags[blockIdx.x] == 0u) return;  // (whole workgroup; no barrier has been passed)
+  // One byte array carved per path (static LDS is the maximum over both):
+  //   fp16 path:  state planes [2 buffers][2 planes] | feature planes [2][3] | W planes in fragment order (48 KB: with
+  //               128 registers of U planes per lane the 24 of W's are re-read each step instead of kept)
+  //   bf16 path:  U plane 2 (fragment order) | state planes [1][3] | feature planes [1][3]   (single-buffered: two
+  //               barriers per step; 160 256 bytes, the CU has 163 840)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[U2L + 3 * PLH2 + 3 * PLX2];
+  __shared__ __attribute__((aligned(16))) float sbias[2][H2];
+  __shared__ float hmax_s[8];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 32 + g * 4;                  // this lane's units: n0 + 16 mt + r, mt = 0, 1
+  constexpr bool hs_last = AUX == 3;
+  const int xu = tid >> 5, xf = tid & 31;          // the feature value this lane converts each step
+  const int xb = blockIdx.x * 16 + xu;
+  const int xbc = (!RAGGED || xb < B) ? xb : B - 1;
+
+  if (tid < H2) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
+  f32x4 hown[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) hown[mt] = ld4(h0 + (size_t)bc * H2 + n0 + 16 * mt);
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+
+  // The fp16 path needs |h| inside fp16's range for the whole scan: see fwd_scan_split_w8 (kernels_split.hip) for the
+  // bound |h_t| <= max(|h0|, 1) + t under gates with z in [0,1]; the workgroup checks its own rows of h0.
+  bool use_h16 = false;
+  if constexpr (F16H) {
+    float hm = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hm = fmaxf(hm, fabsf(hown[mt][r]));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (!(hown[mt][r] == hown[mt][r])) hm = 3.0e38f;   // NaN: no range assumption
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) hm = fmaxf(hm, __shfl_xor(hm, m));
+    if (l == 0) hmax_s[wv] = hm;
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) hm = fmaxf(hm, hmax_s[k2]);
+    use_h16 = __builtin_amdgcn_readfirstlane((int)(hm + (float)Tn + 2.0f < 3.0e4f)) != 0;
+    if (tid == 0) flags[blockIdx.x] = use_h16 ? 0u : 1u;
+    if (!use_h16) return;                            // the bf16 launch behind this one takes the workgroup
+  }
+
+  auto scan = [&](auto h16_tag) __attribute__((always_inline)) {
+  constexpr bool H16 = decltype(h16_tag)::value;
+  constexpr int NPL = H16 ? 2 : 3, NBUF = H16 ? 2 : 1;
+  unsigned char* const hpl = smem + (H16 ? 0 : U2L);                   // [NBUF][NPL][PLH2]
+  unsigned char* const xpl = hpl + NBUF * NPL * PLH2;                  // [NBUF][3][PLX2]
+  u32x4* const u2l = reinterpret_cast<u32x4*>(smem);                   // bf16 path: [(wv*2 + mt)*8 + s][lane]
+  u32x4* const wfl = reinterpret_cast<u32x4*>(xpl + NBUF * 3 * PLX2);  // fp16 path: [(wv*2 + mt)*3 + plane][lane]
+
+  // ---- resident A operands ----------------------------------------------------------------------
+  Frag2h Uh[2][KS2];               // fp16 path
+  u32x4 U0[2][KS2], U1[2][KS2];    // bf16 path: planes 0 and 1 (plane 2 in LDS)
+  Frag3 Wf[2];
+  float u_unscale = 1.0f;
+  {
+    float umax = 0.f;
+    if (H16) {                     // one exact power of two for the wave's rows: largest element into [2^12, 2^13)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+          const float* up = u + (size_t)(wv * 32 + 16 * mt + i) * H2 + 32 * s + 8 * g;
+          const f32x4 a = ld4(up), c = ld4(up + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) umax = fmaxf(umax, fmaxf(fabsf(a[j]), fabsf(c[j])));
+        }
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) umax = fmaxf(umax, __shfl_xor(umax, m));
+    }
+    int e = 0;
+    if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &e);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float u_scale = ldexpf(1.0f, 13 - e);
+    if (H16) u_unscale = ldexpf(1.0f, e - 13);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int nA = wv * 32 + 16 * mt + i;          // A row i of tile mt, K in natural unit order
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const float* up = u + (size_t)nA * H2 + 32 * s + 8 * g;
+        const f32x4 a = ld4(up), c = ld4(up + 4);
+        if (H16) {
+          Uh[mt][s] = split2h8(a * u_scale, c * u_scale);
+        } else {
+          const Frag3 f = split3(a, c);
+          U0[mt][s] = f.p[0]; U1[mt][s] = f.p[1];
+          u2l[((wv * 2 + mt) * KS2 + s) * 64 + l] = f.p[2];
+        }
+      }
+      const float* wp = w + (size_t)nA * F2 + 8 * g;
+      Wf[mt] = split3(ld4(wp), ld4(wp + 4));
+      if (H16) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wfl[((wv * 2 + mt) * 3 + p) * 64 + l] = Wf[mt].p[p];
+      }
+    }
+  }
+
+  auto publish_h = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const unsigned off = (unsigned)(buf * NPL * PLH2 + i * ROWH2 + (n0 + 16 * mt) * 2);
+      if (H16) {
+        uint2 hi, lo;
+        split2h(hown[mt][0], hown[mt][1], hi.x, lo.x); split2h(hown[mt][2], hown[mt][3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(hpl + off) = hi;
+        *reinterpret_cast<uint2*>(hpl + PLH2 + off) = lo;
+      } else {
+        uint2 q0, q1, q2;
+        split_quad(hown[mt], q0, q1, q2);
+        *reinterpret_cast<uint2*>(hpl + off) = q0;
+        *reinterpret_cast<uint2*>(hpl + PLH2 + off) = q1;
+        *reinterpret_cast<uint2*>(hpl + 2 * PLH2 + off) = q2;
+      }
+    }
+  };
+  auto publish_x = [&](int buf, float v) __attribute__((always_inline)) {
+    unsigned short s0, s1, s2;
+    split_one(v, s0, s1, s2);
+    const unsigned off = (unsigned)(buf * 3 * PLX2 + xu * ROWX2 + xf * 2);
+    *reinterpret_cast<unsigned short*>(xpl + off) = s0;
+    *reinterpret_cast<unsigned short*>(xpl + PLX2 + off) = s1;
+    *reinterpret_cast<unsigned short*>(xpl + 2 * PLX2 + off) = s2;
+  };
+  const float* xlane = x + (size_t)xbc * F2 + xf;          // this lane's value of frame t: xlane[t * B * F]
+  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * B * F2]; };
+  const unsigned lane_hs = (unsigned)b * H2 + n0;
+  auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
+    if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
+    if (valid) {
+      float* ho = hs_last ? hs + lane_hs : hs + (size_t)t * B * H2 + lane_hs;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) st4(ho + 16 * mt, hown[mt]);
+      if (AUX == 2) {
+        float* po = zs + (size_t)t * B * H2 + lane_hs;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) st4(po + 16 * mt, aux[mt]);
+      }
+    }
+  };
+
+  __syncthreads();                                   // sbias staged; bf16 path: every wave's plane-2 fragments written
+  publish_h(0);
+  publish_x(0, load_x(0));
+  float xnext = load_x(Tn > 1 ? 1 : 0);              // frame t+1, published during step t
+  __syncthreads();
+
+  f32x4 aux_prev[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int t = 0; t < Tn; ++t) {
+    const int cur = H16 ? (t & 1) : 0, nxt = H16 ? (cur ^ 1) : 0;
+    const float xpub = xnext;
+    xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
+    const unsigned char* hp = hpl + cur * NPL * PLH2;
+    const unsigned char* xp = xpl + cur * 3 * PLX2;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2] = {z4, z4}, alo[2] = {z4, z4};        // W.x (+ U.h on the bf16 path): big / small terms
+    f32x4 ah[2] = {z4, z4}, ahl[2] = {z4, z4};       // fp16 path: U.h scaled by 2^k
+    constexpr int KB = H16 ? 4 : 2;                  // K-steps per fragment batch
+    // every fragment read of a batch is ISSUED, each into registers of its own, before the first MFMA that reads
+    // one; a batch's registers are reloaded only after its MFMAs have retired (operand rule)
+    {
+      // ---- batch W: the frame product W.x_t (.cu:356) ---------------------------------------------------------
+      Frag3 xB, Wl[2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(xp + p * PLX2 + i * ROWX2 + 16 * g);
+      if (H16) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) Wl[mt].p[p] = wfl[((wv * 2 + mt) * 3 + p) * 64 + l];
+      }
+      if (t > 0) store_step(t - 1, aux_prev);        // h_{t-1} (+ its pre-activation): issued during the LDS round trip
+      if (H16) publish_x(nxt, xpub);                 // (double-buffered: the next frame's planes go out here)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) mfma6_hl(H16 ? Wl[mt] : Wf[mt], xB, a[mt], alo[mt]);
+      __builtin_amdgcn_sched_barrier(0);
+      float touch = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) touch += a[mt][0] + alo[mt][0];
+      if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
+      if (H16) {                                     // fp16 path: W.x is complete; one sum instead of two accumulators
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt] += alo[mt];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < KS2; k0 += KB) {
+      Frag2h hH[KB];
+      Frag3 hB[KB];
+      u32x4 U2[2][KB];
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+        const unsigned o = (unsigned)(i * ROWH2 + 64 * (k0 + s) + 16 * g);
+        if (H16) {
+          hH[s].hi = *reinterpret_cast<const u32x4*>(hp + o);
+          hH[s].lo = *reinterpret_cast<const u32x4*>(hp + PLH2 + o);
+        } else {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) hB[s].p[p] = *reinterpret_cast<const u32x4*>(hp + p * PLH2 + o);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) U2[mt][s] = u2l[((wv * 2 + mt) * KS2 + k0 + s) * 64 + l];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KB; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (H16) {
+            mfma3h_hl(Uh[mt][k0 + s], hH[s], ah[mt], ahl[mt]);                          // .cu:368, scaled by 2^k
+          } else {                                                                       // .cu:368, six terms
+            alo[mt] = mfma_bf16(U2[mt][s], hB[s].p[0], alo[mt]);
+            alo[mt] = mfma_bf16(U1[mt][k0 + s], hB[s].p[1], alo[mt]);
+            alo[mt] = mfma_bf16(U0[mt][k0 + s], hB[s].p[2], alo[mt]);
+            alo[mt] = mfma_bf16(U1[mt][k0 + s], hB[s].p[0], alo[mt]);
+            alo[mt] = mfma_bf16(U0[mt][k0 + s], hB[s].p[1], alo[mt]);
+            a[mt] = mfma_bf16(U0[mt][k0 + s], hB[s].p[0], a[mt]);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks MFMAs below the read)
+      float touch = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) touch += H16 ? (ah[mt][0] + ahl[mt][0]) : (a[mt][0] + alo[mt][0]);
+      if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: .cu:55-58 -----------------------------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 pre = H16 ? a[mt] + (ah[mt] + ahl[mt]) * u_unscale : a[mt] + alo[mt];
+      const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 16 * mt]);
+      const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 16 * mt]);
+      f32x4 zq, cq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = gate_act<GATE>(pre[r] + bzq[r]);
+        const float c = ftanh(pre[r] + bhq[r]);
+        hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
+        zq[r] = z; cq[r] = c;
+      }
+      if (AUX == 1 && valid) {                       // reference operator outputs: stored at once
+        const size_t o = (size_t)t * B * H2 + lane_hs + 16 * mt;
+        st4(zs + o, zq); st4(cs + o, cq);
+      }
+      aux_prev[mt] = pre;
+    }
+    if (!H16) {                                      // single-buffered planes: everyone has read h_{t-1}, x_t by now
+      lds_barrier();
+      publish_x(0, xpub);
+    }
+    publish_h(nxt);
+    lds_barrier();
+  }
+  store_step(Tn - 1, aux_prev);
+  {                                                  // the weight fragments stay allocated through the last step
+    float probe = hown[0][0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (!H16) keep_alive(probe, Wf[mt]);
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        if (H16) asm volatile("" : "+v"(probe) : "v"(Uh[mt][s].hi), "v"(Uh[mt][s].lo));
+        else asm volatile("" : "+v"(probe) : "v"(U0[mt][s]), "v"(U1[mt][s]));
+      }
+    }
+  }
+  };
+  if constexpr (F16H) scan(std::true_type{}); else scan(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+// Reverse scan, recurrence only: per step t EW of the lane's 8 elements (z, c recomputed from the saved
+// pre-activation under PREACT, else read) -> d_pre_t to the workspace -> chain  d_h = z*g + U^T d_pre  for the
+// wave's own 32 units over all eight K-steps.
+//
+// Where U^T lives decides everything here.  Three bf16 planes are 384 KB; two of them in registers (128 per lane at
+// two waves per SIMD) plus one in LDS was built first and could not be compiled without spilling ~70 registers of
+// weight fragments inside the loop (the compiler wants ~160 registers for the rest of the kernel; one wave per SIMD
+// with 512 registers did no better: the MFMA operands have to pass through the 256 architectural VGPRs).  So the
+// chain runs on fp16 TWO-plane operands, hi = fp16(v), lo = fp16(v - hi), three MFMAs per K-step (lo.hi, hi.lo,
+// hi.hi) like the forward's state product: U^T's hi plane in registers (64 per lane), its lo plane in LDS in
+// fragment order (128 KB, each wave re-reading only its own fragments).  U^T is bounded and pre-scaled by one exact
+// power of two per wave.  d_pre is NOT bounded -- the reason kernels_split.hip keeps bf16 planes for gradients: a
+// small-magnitude gradient falls into fp16's subnormal range -- so every (utterance, producer wave) slice of 32
+// values is scaled by its own exact power of two that puts the slice's largest magnitude in [2^11, 2^12) before
+// the split: planes then resolve 2^-22 of the slice's largest element, which is what a dot product with that slice
+// needs.  A producer wave's 32 units are exactly one K-step of the chain, so the consumer un-scales each K-step's
+// product with ONE fma per result (dh += partial * 2^-k): no cross-wave maximum, no extra barrier.
+// d_bz, d_bh, d_zeta, d_nu partial sums per workgroup.  mode bit 1 (FASTGRNN_FLAG_GRAD_LAST): ghs is [B,H], the
+// gradient of the last state alone.
+template <int GATE, bool PREACT, bool RAGGED>
+__global__ __launch_bounds__(512) void bwd_scan_h256(
+    int Tn, int B, int mode, const float* __restrict__ ghs, const float* __restrict__ hs,
+    const float* __restrict__ aux0, const float* __restrict__ aux1, const float* __restrict__ h0,
+    const float* __restrict__ u, const float* __restrict__ bz, const float* __restrict__ bh,
+    const float* __restrict__ zeta, const float* __restrict__ nu,
+    float* __restrict__ d_h0, float* __restrict__ dpre_ws, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[U2L + 2 * PLH2];
+  __shared__ __attribute__((aligned(16))) float sinv[16][8];        // 2^-k of slice (utterance, producer wave)
+  __shared__ __attribute__((aligned(16))) float sbias[2][H2];
+  __shared__ float red[16];
+
+  const bool g_last = (mode & 2) != 0;
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, i = l & 15, g = l >> 4;
+  const int b = blockIdx.x * 16 + i;
+  const bool valid = !RAGGED || b < B;
+  const int bc = valid ? b : B - 1;
+  const int n0 = wv * 32 + g * 4;                    // this lane's units: n0 + 16 mt + r
+  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+  if (PREACT && tid < H2) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
+  u32x4* const ulo = reinterpret_cast<u32x4*>(smem); // lo plane of U^T: [(wv*2 + mt)*8 + s][lane]
+  unsigned char* const dpl = smem + U2L;             // [2][PLH2]: hi / lo planes of the scaled d_pre_t, [utterance][unit]
+
+  // ---- resident A operands: d_h[k][b] = sum_n U[n][k] d_pre[b][n]; A row i of tile mt is k = 32w + 16mt + i ----
+  u32x4 UTh[2][KS2];
+  float u_unscale;
+  {
+    f32x4 lo[2][KS2], hi[2][KS2];
+    float umax = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int k = wv * 32 + 16 * mt + i;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[mt][s][j] = u[(size_t)(32 * s + 8 * g + j) * H2 + k];
+          hi[mt][s][j] = u[(size_t)(32 * s + 8 * g + 4 + j) * H2 + k];
+          umax = fmaxf(umax, fmaxf(fabsf(lo[mt][s][j]), fabsf(hi[mt][s][j])));
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) umax = fmaxf(umax, __shfl_xor(umax, m));
+    int e = 0;
+    if (umax > 0.f && umax < 3.0e38f) (void)frexpf(umax, &e);      // umax = f * 2^e, f in [0.5, 1)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float u_scale = ldexpf(1.0f, 13 - e);                      // largest element into [2^12, 2^13)
+    u_unscale = ldexpf(1.0f, e - 13);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const Frag2h f = split2h8(lo[mt][s] * u_scale, hi[mt][s] * u_scale);
+        UTh[mt][s] = f.hi;
+        ulo[((wv * 2 + mt) * KS2 + s) * 64 + l] = f.lo;
+      }
+  }
+
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 sbz[2] = {z4, z4}, sbh[2] = {z4, z4}, dh[2] = {z4, z4};
+  float pz = 0.f, pn = 0.f;
+
+  // Addresses: a wave-uniform step base (scalar registers) + a 32-bit lane offset (the host rejects B*H*4 >= 2^31)
+  const unsigned lane_c = ((unsigned)bc * H2 + n0) * 4u, lane_v = ((unsigned)b * H2 + n0) * 4u;   // BYTE offsets
+  auto ldg = [](const float* base, unsigned off) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
+  };
+  auto stg = [](float* base, unsigned off, f32x4 v) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + off) = v;
+  };
+  struct EwOps { f32x4 g[2], a0[2], a1[2], h[2]; };
+  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    const size_t step = (size_t)t * B * H2;                                  // uniform
+    const float* gt = g_last ? ghs : ghs + step;
+    const float* p0 = aux0 + step;
+    const float* p1 = PREACT ? aux0 : aux1 + step;
+    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)B * H2);         // .cu:478-481
+    const bool g_zero = (g_last && t != Tn - 1) || (RAGGED && !valid);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero: gg, d_pre and
+      // every sum they enter stay exactly zero for them)
+      e.g[mt] = g_zero ? z4 : ldg(gt, lane_c + 64u * mt);
+      e.a0[mt] = ldg(p0, lane_c + 64u * mt);
+      if (!PREACT) e.a1[mt] = ldg(p1, lane_c + 64u * mt);
+      e.h[mt] = ldg(ht, lane_c + 64u * mt);
+    }
+  };
+
+  // ONE operand set: EW(t) consumes it at the top of the step and the requests for EW(t-1) refill it right behind
+  // the step's LDS hand-off (two sets and a loop unrolled by two cost ~40 registers more and spilled)
+  auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    // ---- EW(t): .cu:107-117 ---------------------------------------------------------------------------------
+    f32x4 dpv[2];
+    float amax = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 bzq = z4, bhq = z4;
+      if (PREACT) {
+        bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 16 * mt]);
+        bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 16 * mt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float z, c;
+        if (PREACT) {
+          z = gate_act<GATE>(e.a0[mt][r] + bzq[r]);
+          c = ftanh(e.a0[mt][r] + bhq[r]);
+        } else {
+          z = e.a0[mt][r]; c = e.a1[mt][r];
+        }
+        const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
+        const float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;          // .cu:109
+        const float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;       // .cu:110
+        const float cg = c * gg;
+        sbz[mt][r] += dzp; sbh[mt][r] += dcp;
+        pn += cg; pz += cg - z * cg;                                             // .cu:114-115
+        dpv[mt][r] = dzp + dcp;                                                  // .cu:113
+        dh[mt][r] = z * gg;                                                      // .cu:108: C-in of the chain
+        amax = fmaxf(amax, fabsf(dpv[mt][r]));
+      }
+    }
+    if (valid) {                                     // d_pre_t for the weight-gradient / d_x GEMMs
+      float* o = dpre_ws + (size_t)t * B * H2;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) stg(o, lane_v + 64u * mt, dpv[mt]);
+    }
+    // ---- the slice's power of two: largest |d_pre| of utterance i over this wave's 32 units into [2^11, 2^12) ---
+    amax = fmaxf(amax, __shfl_xor(amax, 16));
+    amax = fmaxf(amax, __shfl_xor(amax, 32));
+    int ex = 12;                                     // all-zero slice (or inf / NaN, which propagate anyway): scale 1
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);       // amax = f * 2^ex, f in [0.5, 1)
+    ex = ex < -112 ? -112 : ex;                      // (2^(12-ex) must stay a normal float)
+    const float dscale = ldexpf(1.0f, 12 - ex);
+    lds_barrier();                                   // every wave has finished reading the planes of step t+1
+    if (g == 0) sinv[i][wv] = ldexpf(u_unscale, ex - 12);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      uint2 hi, lo;
+      split2h(dpv[mt][0] * dscale, dpv[mt][1] * dscale, hi.x, lo.x);
+      split2h(dpv[mt][2] * dscale, dpv[mt][3] * dscale, hi.y, lo.y);
+      const unsigned off = (unsigned)(i * ROWH2 + (n0 + 16 * mt) * 2);
+      *reinterpret_cast<uint2*>(dpl + off) = hi;
+      *reinterpret_cast<uint2*>(dpl + PLH2 + off) = lo;
+    }
+    lds_barrier();
+    // requests for EW(t-1): behind the reads of dh above (they may land in registers the last chain's fragments used)
+    if (t > 0) load_ew(t - 1, e);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain(t): d_h = z*g + U^T d_pre_t (.cu:537): per K-step three fp16 MFMAs per row tile into a fresh
+    //      accumulator, un-scaled into dh by one fma per result -----------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < KS2; ++k) {                  // one K-step per fragment batch
+      Frag2h dB;
+      u32x4 Ul[2];
+      const unsigned o = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
+      dB.hi = *reinterpret_cast<const u32x4*>(dpl + o);
+      dB.lo = *reinterpret_cast<const u32x4*>(dpl + PLH2 + o);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
+      const float inv = sinv[i][k];
+      __builtin_amdgcn_sched_barrier(0);             // all fragment reads of the batch issued before its first MFMA
+      f32x4 pr[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 a = mfma_f16(Ul[mt], dB.hi, z4);                       // small terms first
+        a = mfma_f16(UTh[mt][k], dB.lo, a);
+        pr[mt] = mfma_f16(UTh[mt][k], dB.hi, a);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // reading the partial products retires the batch before its registers are reloaded (operand rule)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r], inv, dh[mt][r]);
+      // (pinned here: without a use at this point the optimiser sinks the fmas below the next batches' reads and
+      // the completion read with them)
+      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  EwOps ea;
+  __syncthreads();                                   // sbias, lo-plane fragments
+  load_ew(Tn - 1, ea);
+  for (int t = Tn - 1; t >= 0; --t) step(t, ea);
+  // ---- flush ---------------------------------------------------------------------------------
+  if (valid) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) stg(d_h0, lane_v + 64u * mt, dh[mt]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = sbz[mt][r], c = sbh[mt][r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
+      if (i == 0) {
+        float* pb = part + (size_t)blockIdx.x * SLAB2;
+        pb[n0 + 16 * mt + r] = a;
+        pb[H2 + n0 + 16 * mt + r] = c;
+      }
+    }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
+  if (l == 0) { red[wv] = pz; red[8 + wv] = pn; }
+  __syncthreads();
+  if (tid == 0) {
+    float* pzn = part + (size_t)blockIdx.x * SLAB2 + 2 * H2;
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += red[k]; c += red[8 + k]; }
+    pzn[0] = a; pzn[1] = c;
+  }
+  {
+    float probe = dh[0][0];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) asm volatile("" : "+v"(probe) : "v"(UTh[mt][s]));
+  }
+}
+
+// bias / zeta / nu gradients: fixed-order sum over workgroups
+__global__ __launch_bounds__(1024) void reduce_h256_small(int nwg, const float* __restrict__ part,
+                                                          const float* __restrict__ zeta, const float* __restrict__ nu,
+                                                          float* __restrict__ d_bz, float* __restrict__ d_bh,
+                                                          float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+  __shared__ float sm[16][64];
+  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;               // 0 .. 2*256+1
+  float a = 0.f;
+  if (idx < 2 * H2 + 2) {
+    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * SLAB2 + idx] : 0.f; }
+      a += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  sm[pid][o] = a;
+  __syncthreads();
+  if (pid == 0 && idx < 2 * H2 + 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sm[j][o];
+    if (idx < H2) d_bz[idx] = t;
+    else if (idx < 2 * H2) d_bh[idx - H2] = t;
+    else if (idx == 2 * H2) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
+    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                          // .cu:117,545
+  }
+}
+
+struct H256BwdWs { size_t part, dpre, tn, total; };
+H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
+  const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
+  H256BwdWs L; size_t o = 0;
+  L.part = o; o += align256(nwg * SLAB2 * 4);
+  L.dpre = o; o += align256(TB * H2 * 4);
+  const size_t tn_u = tn_gemm_big_ws(TB, H2, H2), tn_w = tn_gemm_big_ws(TB, H2, F2);
+  L.tn = o; o += tn_u > tn_w ? tn_u : tn_w;
+  L.total = o;
+  return L;
+}
+
+template <int GATE>
+void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
+                void* cs, void* ws, hipStream_t s) {
+  dim3 grid((d.B + 15) / 16), block(512);
+  const bool ragged = (d.B % 16) != 0;
+  const int aux = (d.flags & FASTGRNN_FLAG_HS_LAST) ? 3 : (zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1));
+  unsigned* flags = reinterpret_cast<unsigned*>(ws);
+  auto go = [&](auto kern) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
+                       (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
+                       (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags);
+  };
+  // fp16 two-plane state product only for gates that keep z in [0,1] (see fwd_scan_split_w8); FWD_BF16X3: A/B
+  constexpr bool BOUNDED = GATE == FASTGRNN_NL_SIGMOID || GATE == FASTGRNN_NL_QUANT_SIGM || GATE == FASTGRNN_NL_QUANT_SIGM4;
+  const bool h16 = BOUNDED && !(d.flags & FASTGRNN_FLAG_FWD_BF16X3);
+  auto pick = [&](auto aux_tag) __attribute__((always_inline)) {
+    constexpr int A = decltype(aux_tag)::value;
+    if constexpr (BOUNDED) {
+      if (h16) {                                     // fp16 launch, then the bf16 one for workgroups it turned down
+        if (ragged) { go(fwd_scan_h256<GATE, A, true, 1>); go(fwd_scan_h256<GATE, A, true, 2>); }
+        else        { go(fwd_scan_h256<GATE, A, false, 1>); go(fwd_scan_h256<GATE, A, false, 2>); }
+        return;
+      }
+    }
+    if (ragged) go(fwd_scan_h256<GATE, A, true, 0>); else go(fwd_scan_h256<GATE, A, false, 0>);
+  };
+  if (aux == 3) pick(std::integral_constant<int, 3>{});
+  else if (aux == 2) pick(std::integral_constant<int, 2>{});
+  else if (aux == 1) pick(std::integral_constant<int, 1>{});
+  else pick(std::integral_constant<int, 0>{});
+}
+
+template <int GATE>
+void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                const void* a0, const void* a1, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
+  const H256BwdWs L = h256_bwd_layout(d);
+  char* base = reinterpret_cast<char*>(ws);
+  float* part = (float*)(base + L.part); float* dpre = (float*)(base + L.dpre); float* tn = (float*)(base + L.tn);
+  const int nwg = (d.B + 15) / 16;
+  const bool ragged = (d.B % 16) != 0, preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  auto go = [&](auto kern) __attribute__((always_inline)) {
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 0, s, d.T, d.B, (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 2 : 0,
+                       (const float*)ghs, (const float*)hs, (const float*)a0, (const float*)a1, (const float*)h0,
+                       (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
+                       (const float*)p.nu, (float*)g.d_h0, dpre, part);
+  };
+  if (preact) { if (ragged) go(bwd_scan_h256<GATE, true, true>); else go(bwd_scan_h256<GATE, true, false>); }
+  else        { if (ragged) go(bwd_scan_h256<GATE, false, true>); else go(bwd_scan_h256<GATE, false, false>); }
+  hipLaunchKernelGGL(reduce_h256_small, dim3((2 * H2 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
+                     (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
+  const size_t TB = (size_t)d.T * d.B;
+  // dU = d_pre^T . H_prev (rows of t = 0 are h0, the rest hs[t-1]);  dW = d_pre^T . X   (.cu:539-540 over all steps)
+  tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
+  tn_gemm_big_run(TB, H2, F2, dpre, H2, (const float*)x, (const float*)x, (size_t)0, F2, tn, (float*)g.d_w, F2, s);
+  // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N])
+  rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, g.d_x, false, false, s);
+}
+
+}  // namespace
+
+bool h256_shape(const fastgrnn_desc& d) {
+  // B < 2^21: a step's rows are addressed with 32-bit lane offsets (B*H*4 bytes < 2^31)
+  return d.w_rank == 0 && d.u_rank == 0 && d.H == H2 && d.F == F2 && d.B < (1 << 21);
+}
+
+// time-major fp32 sequences, every gate, both saved-tensor contracts, full or last-state outputs / gradients
+bool h256_supported(const fastgrnn_desc& d, int direction) {
+  if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
+  if (d.flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) return false;
+  if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
+  const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  return d.gate_nl <= FASTGRNN_NL_TANH || direction == 0 || preact;
+}
+
+size_t h256_backward_ws(const fastgrnn_desc& d) { return h256_bwd_layout(d).total; }
+// one word per workgroup: "my rows of h0 are outside the fp16 path's range" (fwd_scan_h256 MODE 1 -> MODE 2)
+size_t h256_forward_ws(const fastgrnn_desc& d) { return align256((size_t)((d.B + 15) / 16) * sizeof(unsigned)); }
+
+int h256_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
+                 void* cs, void* ws, hipStream_t s) {
+  if (!ws) return FASTGRNN_ERR_WORKSPACE;
+  switch (d.gate_nl) {
+    case FASTGRNN_NL_SIGMOID: launch_fwd<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, ws, s); break;
+    case FASTGRNN_NL_RELU: launch_fwd<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, ws, s); break;
+    case FASTGRNN_NL_TANH: launch_fwd<FASTGRNN_NL_TANH>(d, p, x, h0, hs, zs, cs, ws, s); break;
+    case FASTGRNN_NL_QUANT_TANH: launch_fwd<FASTGRNN_NL_QUANT_TANH>(d, p, x, h0, hs, zs, cs, ws, s); break;
+    case FASTGRNN_NL_QUANT_SIGM: launch_fwd<FASTGRNN_NL_QUANT_SIGM>(d, p, x, h0, hs, zs, cs, ws, s); break;
+    default: launch_fwd<FASTGRNN_NL_QUANT_SIGM4>(d, p, x, h0, hs, zs, cs, ws, s); break;
+  }
+  return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
+}
+
+int h256_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                  const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
+  switch (d.gate_nl) {
+    case FASTGRNN_NL_SIGMOID: launch_bwd<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_RELU: launch_bwd<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_TANH: launch_bwd<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_QUANT_TANH: launch_bwd<FASTGRNN_NL_QUANT_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    case FASTGRNN_NL_QUANT_SIGM: launch_bwd<FASTGRNN_NL_QUANT_SIGM>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+    default: launch_bwd<FASTGRNN_NL_QUANT_SIGM4>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
+  }
+  return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
+}
+
+}  // namespace fastgrnn

@@ -25,6 +25,7 @@ the HIP kernels; there is no eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 
@@ -114,19 +115,41 @@ def _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu
     for t in tensors:
         if t.dtype != dtype:
             raise RuntimeError("fastgrnn: all operands must share dtype %s (got %s)" % (dtype, t.dtype))
-    desc = _lib.Desc(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), _DTYPES[io_dtype], int(flags))
+    desc = _plan(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), _DTYPES[io_dtype], int(flags))
     params = _lib.Params(_ptr(None if w_lr else w), _ptr(None if u_lr else u),
                          _ptr(w1 if w_lr else None), _ptr(w2 if w_lr else None),
                          _ptr(u1 if u_lr else None), _ptr(u2 if u_lr else None),
                          _ptr(bias_gate), _ptr(bias_update), _ptr(zeta), _ptr(nu))
-    return desc, params, w_lr, u_lr
+    return desc, params, w_lr, u_lr          # desc: the cached plan tuple (struct, paths, workspace sizes)
+
+
+# Scratch workspace, kept per (device, stream) and grown on demand: its contents never outlive a call and every use
+# is stream-ordered, so consecutive calls on one stream can share it (a fresh torch.empty per call was a few
+# microseconds of host time per step; the 8-GPU step adds the collective's latency on top of whatever the host spends)
+_ws_cache = {}
 
 
 def _workspace(nbytes, device):
     if nbytes == 0:
         return None, C.c_void_p(None)
-    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
     return ws, C.c_void_p(ws.data_ptr())
+
+
+@functools.lru_cache(maxsize=1024)
+def _plan(T, B, F, H, rw, ru, gate_nl, update_nl, dtype_code, flags):
+    """Everything about a descriptor that does not depend on the tensors: the C struct itself, the kernel family
+    each direction dispatches to and the workspace sizes (pure functions of the descriptor in the C ABI).  One
+    dictionary lookup per call instead of four ctypes round trips."""
+    lib = _lib.load()
+    desc = _lib.Desc(T, B, F, H, rw, ru, int(gate_nl), int(update_nl), dtype_code, int(flags))
+    return (desc, lib.fastgrnn_hip_kernel_path(C.byref(desc), 0), lib.fastgrnn_hip_kernel_path(C.byref(desc), 1),
+            int(lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))),
+            int(lib.fastgrnn_hip_backward_workspace_bytes(C.byref(desc))))
 
 
 def _stream(device):
@@ -135,9 +158,8 @@ def _stream(device):
 
 def kernel_path(T, B, F, H, w_rank=0, u_rank=0, gate_nl=0, update_nl=2, dtype=torch.float32,
                 direction=0, flags=0):
-    """0 = generic scan, 1 = MFMA-tiled scan (pure function of the descriptor)."""
-    desc = _lib.Desc(T, B, F, H, w_rank, u_rank, gate_nl, update_nl, _DTYPES[dtype], flags)
-    return _lib.load().fastgrnn_hip_kernel_path(C.byref(desc), direction)
+    """0 = generic scan, 1 = fp32-MFMA scan, 2 = split-precision scan (pure function of the descriptor; cached)."""
+    return _plan(T, B, F, H, w_rank, u_rank, int(gate_nl), int(update_nl), _DTYPES[dtype], int(flags))[1 + int(direction)]
 
 
 def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1, w2, u1, u2,
@@ -169,8 +191,9 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     if h0.dtype != pdt:
         raise RuntimeError("input and hidden state dtypes differ" if pdt == input.dtype
                            else "bfloat16 sequences take a float32 hidden state")
-    desc, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
+    plan, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
                                    input.dtype, gate_nl, update_nl, flags)
+    desc = plan[0]
     dev = input.device
     oshape = ((B, T, H) if batch_major else (T, B, H)) if unrolled else (B, H)
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
@@ -185,16 +208,15 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         if preact and desc.w_rank and desc.u_rank:
             # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step
             cs = torch.empty((T, B, desc.w_rank + desc.u_rank), dtype=pdt, device=dev)
-        nbytes = lib.fastgrnn_hip_forward_workspace_bytes(C.byref(desc))
+        # (kernel path 2 needs its forward workspace only when no auxiliary output is requested)
+        nbytes = 0 if (plan[1] == 2 and zs is not None and plan[3] > 65536) else plan[3]
         ws, wsp = _workspace(nbytes, dev)
         fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
         with _Timed("forward", dev):
             st = fn(C.byref(desc), C.byref(params), _ptr(input), _ptr(h0), _ptr(hs), _ptr(zs), _ptr(cs),
                     wsp, nbytes, _stream(dev))
         _lib.check(st, "fastgrnn forward_unroll" if unrolled else "fastgrnn forward")
-        # ws was allocated by torch's caching allocator on this same (current) stream, so
-        # its reuse after this function returns is stream-ordered behind the launches above.
-        del ws
+        del ws                   # (cached per stream: reuse by the next call is stream-ordered behind these launches)
     if preact:                   # zs holds the pre-activation W.x + U.h
         return [hs, zs] if cs is None else [hs, zs, cs]
     return [hs, zs, cs] if want_gates else [hs]
@@ -240,9 +262,10 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         if t.dtype != want:
             raise RuntimeError("fastgrnn backward: operand dtypes differ")
     # biases are not needed by the backward when z, h_prime are given: pass zeta as a dummy
-    desc, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2,
+    plan, params, w_lr, u_lr = _describe(T, B, F, H, w, u, w1, w2, u1, u2,
                                          bias_gate if preact else zeta, bias_update if preact else zeta,
                                          zeta, nu, dt, gate_nl, update_nl, flags)
+    desc = plan[0]
     dev = input.device
     with torch.cuda.device(dev):
         mk = lambda *s: torch.empty(s, dtype=pdt, device=dev)
@@ -268,7 +291,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         del flat, views
         grads = _lib.Grads(_ptr(d_input), _ptr(d_bz), _ptr(d_bh), _ptr(d_zeta), _ptr(d_nu), _ptr(d_old_h),
                            _ptr(d_w), _ptr(d_u), _ptr(d_w1), _ptr(d_w2), _ptr(d_u1), _ptr(d_u2))
-        nbytes = lib.fastgrnn_hip_backward_workspace_bytes(C.byref(desc))
+        nbytes = plan[4]
         ws, wsp = _workspace(nbytes, dev)
         with _Timed("backward", dev):
             if unrolled:
@@ -280,9 +303,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                                                _ptr(h0), _ptr(z), _ptr(h_prime), C.byref(grads), wsp, nbytes,
                                                _stream(dev))
         _lib.check(st, "fastgrnn backward_unroll" if unrolled else "fastgrnn backward")
-        # ws was allocated by torch's caching allocator on this same (current) stream, so
-        # its reuse after this function returns is stream-ordered behind the launches above.
-        del ws
+        del ws                   # (cached per stream: reuse by the next call is stream-ordered behind these launches)
     return [d_input, d_bz, d_bh, d_zeta, d_nu, d_old_h, d_w, d_u, d_w1, d_w2, d_u1, d_u2]
 
 

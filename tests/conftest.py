@@ -34,7 +34,36 @@ def load_golden(name):
     return g
 
 
-ALL_GOLDEN = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+# single-layer fixtures (run_case) and whole-model fixtures (run_stack_case: layers chained + head + loss)
+ALL_GOLDEN = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and "_stack2_" not in f)
+STACK_GOLDEN = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and "_stack2_" in f)
+
+
+def load_stack_golden(name):
+    """Whole-model fixture: per-layer parameters / gradients converted to the boundary's [out,in] layout."""
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    hidden = [int(h) for h in d["meta_hidden"]]
+    g = {k: d[k] for k in ("x", "labels", "scores", "loss", "dx", "h_last", "fc_w", "fc_b", "dfc_w", "dfc_b")}
+    g["dtype"] = str(d["meta_dtype"])
+    g["hidden"] = hidden
+    layers = []
+    for l in range(len(hidden)):
+        p, dp = {}, {}
+        for cpu, bnd in (("W", "w"), ("U", "u")):
+            p[bnd] = np.ascontiguousarray(d["l%d_%s" % (l, cpu)].T)
+            dp["d_" + bnd] = np.ascontiguousarray(d["l%d_d%s" % (l, cpu)].T)
+        for k in ("bias_gate", "bias_update", "zeta", "nu"):
+            p[k] = d["l%d_%s" % (l, k)]
+            dp["d_" + k] = d["l%d_d%s" % (l, k)]
+        layers.append((p, dp))
+    g["layers"] = layers
+    g["name"] = name
+    return g
+
+
+@pytest.fixture(params=STACK_GOLDEN)
+def stack_golden(request):
+    return load_stack_golden(request.param)
 
 
 @pytest.fixture(params=ALL_GOLDEN)

@@ -72,7 +72,60 @@ def run_case(name, T, B, F, H, dtype, seed, wRank=None, uRank=None, gate="sigmoi
     print("%-28s T=%d B=%d F=%d H=%d %s -> %.1f KB" % (name, T, B, F, H, dtype, os.path.getsize(path) / 1024))
 
 
+def run_stack_case(name, T, B, F, hidden, C, dtype, seed):
+    """The reference's default model (trainingConfig.py:12-15: two dense layers 32 -> 256 -> 128) as
+    RNNClassifierModel.forward chains it (model.py:196-203: layer l's [T,B,H] output is layer l+1's input;
+    :226-230: Linear on the LAST state, then log_softmax) with the trainer's loss (trainClassifier.py:154,236:
+    nn.NLLLoss()).  The cells are the reference's; the loop over layers and time is written here because its
+    own FastGRNN wrapper raises with FastGRNNCell.  Stores inputs, every layer's parameters
+    (CPU layout) and gradients, the loss, the keyword scores and d_x."""
+    torch.manual_seed(seed)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    sizes = [F] + list(hidden)
+    cells = [rnn.FastGRNNCell(sizes[l], sizes[l + 1]).to(tdt) for l in range(len(hidden))]
+    with torch.no_grad():
+        for c in cells:
+            c.bias_gate.add_(0.5 * torch.randn_like(c.bias_gate))
+            c.bias_update.add_(0.5 * torch.randn_like(c.bias_update))
+            c.zeta.fill_(0.7)
+            c.nu.fill_(-2.5)
+    head = torch.nn.Linear(hidden[-1], C).to(tdt)
+    x = torch.randn(T, B, F, dtype=tdt, requires_grad=True)
+    labels = torch.randint(0, C, (B,))
+    seq = x
+    for c in cells:                                   # model.py:196-203
+        h = torch.zeros(B, c.state_size, dtype=tdt)
+        outs = []
+        for t in range(T):                            # rnn.py:657-660
+            h = c(seq[t], h)
+            outs.append(h)
+        seq = torch.stack(outs, 0)
+    scores = torch.log_softmax(head(seq[-1]), dim=1)  # model.py:226-230
+    loss = torch.nn.NLLLoss()(scores, labels)         # trainClassifier.py:154,236
+    loss.backward()
+    out = {"x": x.detach().numpy(), "labels": labels.numpy(), "scores": scores.detach().numpy(),
+           "loss": loss.detach().numpy(), "dx": x.grad.numpy(), "h_last": seq[-1].detach().numpy(),
+           "fc_w": head.weight.detach().numpy(), "fc_b": head.bias.detach().numpy(),
+           "dfc_w": head.weight.grad.numpy(), "dfc_b": head.bias.grad.numpy()}
+    for l, c in enumerate(cells):
+        for pname, par in c.named_parameters():
+            out["l%d_%s" % (l, pname)] = par.detach().numpy()
+            out["l%d_d%s" % (l, pname)] = par.grad.numpy()
+    out["meta_dtype"] = np.array(dtype)
+    out["meta_hidden"] = np.array(hidden)
+    out["meta_torch"] = np.array(torch.__version__)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s T=%d B=%d F=%d hidden=%s %s -> %.1f KB" % (name, T, B, F, hidden, dtype, os.path.getsize(path) / 1024))
+
+
 def main():
+    only = sys.argv[1:]                               # optional: names of the cases to (re)generate
+    if only:
+        global run_case, run_stack_case
+        _rc, _rs = run_case, run_stack_case
+        run_case = lambda name, *a, **k: _rc(name, *a, **k) if name in only else None
+        run_stack_case = lambda name, *a, **k: _rs(name, *a, **k) if name in only else None
     # G1 tiny, non-zero h0, randomised biases/zeta/nu
     run_case("g1_tiny_f64", 5, 3, 4, 8, "f64", 1, nonzero_h0=True, randomize_scalars=True)
     # G2 north-star shape (reference init) in fp32 and (randomised scalars) fp64
@@ -95,6 +148,11 @@ def main():
     run_case("g8_single_f64", 1, 1, 32, 128, "f64", 11, nonzero_h0=True, randomize_scalars=True)
     # G9 second north-star-width case with B=17 (ragged against the 16-utterance MFMA tile)
     run_case("g9_ragged17_f32", 23, 17, 32, 128, "f32", 12, nonzero_h0=True, randomize_scalars=True)
+    # G10 / G11: the two layers of the reference's default stack (trainingConfig.py:12-15), each on its own
+    run_case("g10_stack_l1_f32", 99, 4, 32, 256, "f32", 13, randomize_scalars=True)
+    run_case("g11_stack_l2_f32", 99, 4, 256, 128, "f32", 14, randomize_scalars=True)
+    # G12: the whole default model -- both layers chained, last-state Linear, log_softmax, NLLLoss
+    run_stack_case("g12_stack2_f64", 99, 4, 32, (256, 128), 12, "f64", 15)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,251 @@
+"""GPU tests for the reference's default stack (trainingConfig.py:12-15: dense 32 -> 256 -> 128, model.py:196-203):
+the wide-input layer (H=128, F=256 and its siblings F=64/128: recurrence-only scans + batched split-precision GEMMs),
+the H=256 layer, and the layers chained through ``kws_amd.RNNClassifierModel`` against the fixture made from the
+reference's own cells (tests/golden/g12_stack2_f64.npz) and the fp64 oracle.  All through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fastgrnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from kws_amd import FastGRNNCUDA, RNNClassifierModel, _lib, fastgrnn_cuda
+DEV = "cuda:0"
+NAMES = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _P(p):
+    return {k: _t(v) for k, v in p.items()}
+
+
+def _run(x, h0, G, p, gate=0, flags=0, preact=False):
+    """forward_unroll + backward_unroll; returns hs, aux list, grads (torch tensors on the device)."""
+    P = _P(p)
+    e = torch.empty(0)
+    if preact:
+        flags |= _lib.FLAG_SAVE_PREACT
+    outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0,
+                                        gate, e, e, e, e, flags=flags)
+    gr = fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1],
+                                       outs[1] if preact else outs[2], h0, e, e, e, e, gate, flags=flags,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    torch.cuda.synchronize()
+    return outs, gr
+
+
+def _oracle(x, G, p, h0, gate="sigmoid"):
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64, G64, h64 = x.astype(np.float64), G.astype(np.float64), h0.astype(np.float64)
+    hs, zs, cs = O.unroll_forward(x64, p64, h64, gate=gate)
+    return hs, zs, cs, O.unroll_backward(G64, x64, hs, zs, cs, p64, h64, gate=gate)
+
+
+def _check(gr, g_o, tol=2e-5):
+    errs = {}
+    for n, o in zip(NAMES, gr[:8]):
+        ref = g_o[n]
+        errs[n] = float(np.abs(o.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, (bad, errs)
+    return errs
+
+
+WIDE = [  # T, B, F, H, preact
+    (99, 64, 256, 128, True), (99, 50, 256, 128, True), (23, 37, 256, 128, False), (12, 16, 128, 128, True),
+    (7, 33, 64, 128, True), (1, 5, 256, 128, True), (2, 1, 256, 128, False), (6, 130, 128, 128, False),
+    (99, 32, 32, 256, True), (24, 37, 32, 256, True), (9, 16, 32, 256, False), (1, 3, 32, 256, True), (2, 50, 32, 256, False),
+]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: "T%dB%dF%dH%d%s" % (c[0], c[1], c[2], c[3], "p" if c[4] else "r"))
+def test_stack_layer_shapes_on_the_matrix_pipe_vs_oracle(case):
+    T, B, F, H, preact = case
+    flags = _lib.FLAG_SAVE_PREACT if preact else 0
+    for direction in (0, 1):
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=direction, flags=flags) == 2, (case, direction)
+    rng = np.random.default_rng(1000 + T * 7 + B + F)
+    p = O.make_params(F, H, dtype=np.float32, seed=31, randomize_scalars=True)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    outs, gr = _run(_t(x), _t(h0), _t(G), p, preact=preact)
+    hs_o, zs_o, cs_o, g_o = _oracle(x, G, p, h0)
+    assert np.abs(outs[0].cpu().numpy() - hs_o).max() <= 1e-5
+    if preact:
+        p64 = {k: v.astype(np.float64) for k, v in p.items()}
+        hprev = np.concatenate([h0[None].astype(np.float64), hs_o[:-1]], 0)
+        pre_o = x.astype(np.float64) @ p64["w"].T + hprev @ p64["u"].T
+        assert np.abs(outs[1].cpu().numpy() - pre_o).max() <= 1e-5
+    else:
+        assert np.abs(outs[1].cpu().numpy() - zs_o).max() <= 1e-5 and np.abs(outs[2].cpu().numpy() - cs_o).max() <= 1e-5
+    _check(gr, g_o)
+
+
+@pytest.mark.parametrize("F,H", [(256, 128), (32, 256)])
+@pytest.mark.parametrize("gate", ["tanh", "relu", "quantSigm"])
+def test_stack_layer_shapes_other_gates(F, H, gate):
+    T, B = 8, 37
+    code = O.GATE_CODES[gate]
+    rng = np.random.default_rng(5)
+    p = O.make_params(F, H, dtype=np.float32, seed=33, randomize_scalars=True)
+    for k in ("w", "u"):
+        p[k] = (0.3 * p[k]).astype(np.float32)
+    p["bias_gate"] = (0.3 * p["bias_gate"] - 0.1).astype(np.float32)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, direction=1, flags=_lib.FLAG_SAVE_PREACT) == 2
+    outs, gr = _run(_t(x), _t(h0), _t(G), p, gate=code, preact=True)
+    hs_o, zs_o, cs_o, g_o = _oracle(x, G, p, h0, gate=gate)
+    assert (np.abs(outs[0].cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    if gate != "tanh":     # piecewise-linear gates: same mask as the kernel (the oracle in fp32 on the kernel's own states)
+        pre = outs[1].cpu().numpy()
+        zk = O.nonlinearity(pre + p["bias_gate"], gate).astype(np.float32)
+        ck = np.tanh(pre + p["bias_update"]).astype(np.float32)
+        g_o = O.unroll_backward(G, x, outs[0].cpu().numpy(), zk, ck, p, h0, gate=gate)
+        _check(gr, g_o, 5e-5)
+    else:
+        _check(gr, g_o)
+
+
+@pytest.mark.parametrize("F,H", [(256, 128), (32, 256)])
+def test_stack_layer_batch_major_and_last_state_contracts(F, H):
+    """FLAG_BATCH_MAJOR is bit-equal to the time-major run; FLAG_GRAD_LAST equals the dense zero-padded gradient;
+    FLAG_HS_LAST returns the last row of the full forward."""
+    T, B = 21, 37
+    rng = np.random.default_rng(9)
+    p = O.make_params(F, H, dtype=np.float32, seed=35, randomize_scalars=True)
+    P = _P(p)
+    e = torch.empty(0)
+    x = _t(rng.standard_normal((T, B, F)).astype(np.float32))
+    h0 = _t((0.5 * rng.standard_normal((B, H))).astype(np.float32))
+    G = _t(rng.standard_normal((T, B, H)).astype(np.float32))
+    outs, gr = _run(x, h0, G, p, preact=True)
+    xb, Gb = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
+    outs_b, gr_b = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR, preact=True)
+    assert torch.equal(outs_b[0].transpose(0, 1), outs[0]) and torch.equal(outs_b[1].transpose(0, 1), outs[1])
+    assert torch.equal(gr_b[0].transpose(0, 1), gr[0])
+    for a, b in zip(gr[1:8], gr_b[1:8]):
+        assert torch.equal(a, b)
+    # last-state gradient
+    Gl = torch.zeros_like(G); Gl[-1] = G[-1]
+    fl = _lib.FLAG_SAVE_PREACT
+    ref = fastgrnn_cuda.backward_unroll(Gl, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1], h0, e, e, e, e,
+                                        0, flags=fl, bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=fl | _lib.FLAG_GRAD_LAST) == 2
+    got = fastgrnn_cuda.backward_unroll(G[-1].contiguous(), x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1],
+                                        h0, e, e, e, e, 0, flags=fl | _lib.FLAG_GRAD_LAST, bias_gate=P["bias_gate"],
+                                        bias_update=P["bias_update"])
+    for a, b in zip(ref[:8], got[:8]):
+        assert torch.equal(a, b)
+    # inference: h_T only
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=0, flags=_lib.FLAG_HS_LAST) == 2
+    hT = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                      e, e, e, e, want_gates=False, flags=_lib.FLAG_HS_LAST)[0]
+    assert hT.shape == (B, H) and float((hT - outs[0][-1]).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("F,H", [(256, 128), (32, 256)])
+def test_stack_layer_full_batch_every_output_vs_fp64_oracle(F, H):
+    """B = 4096, T = 99 for each layer of the default stack: every output against the fp64 oracle."""
+    T, B = 99, 4096
+    rng = np.random.default_rng(77 + F)
+    p = O.make_params(F, H, dtype=np.float32, seed=37, randomize_scalars=True)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    h0 = np.zeros((B, H), np.float32)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT) == 2
+    outs, gr = _run(_t(x), _t(h0), _t(G), p, preact=True)
+    hs_o, zs_o, cs_o, g_o = _oracle(x, G, p, h0)
+    assert np.abs(outs[0].cpu().numpy() - hs_o).max() <= 1e-5
+    errs = _check(gr, g_o)
+    print("stack layer F=%d H=%d full-size errors: %s" % (F, H, {k: "%.2e" % v for k, v in errs.items()}))
+
+
+def _build_model(g, dtype=torch.float32):
+    hidden = g["hidden"]
+    m = RNNClassifierModel("FastGRNNCUDA", g["x"].shape[2], len(hidden), hidden, [None] * len(hidden), [None] * len(hidden),
+                           [1.0] * len(hidden), [1.0] * len(hidden), "sigmoid", "tanh", num_classes=g["fc_w"].shape[0],
+                           device=DEV)
+    with torch.no_grad():
+        for rnn, (p, _) in zip(m.rnn_list, g["layers"]):
+            rnn.W.copy_(_t(p["w"].astype(np.float32))); rnn.U.copy_(_t(p["u"].astype(np.float32)))
+            rnn.bias_gate.copy_(_t(p["bias_gate"].astype(np.float32))); rnn.bias_update.copy_(_t(p["bias_update"].astype(np.float32)))
+            rnn.zeta.copy_(_t(p["zeta"].astype(np.float32))); rnn.nu.copy_(_t(p["nu"].astype(np.float32)))
+        m.hidden2keyword.weight.copy_(_t(g["fc_w"].astype(np.float32)))
+        m.hidden2keyword.bias.copy_(_t(g["fc_b"].astype(np.float32)))
+    return m
+
+
+@pytest.mark.parametrize("fused_head", [False, True])
+def test_two_layer_model_matches_the_reference_cells_chained(stack_golden, fused_head):
+    """kws_amd.RNNClassifierModel (32 -> 256 -> 128 -> Linear -> log_softmax -> NLLLoss) in fp32 against the fp64
+    fixture produced by chaining the reference's own cells: scores, loss and every gradient."""
+    g = stack_golden
+    m = _build_model(g)
+    for l, rnn in enumerate(m.rnn_list):
+        F_l = g["x"].shape[2] if l == 0 else g["hidden"][l - 1]
+        assert fastgrnn_cuda.kernel_path(g["x"].shape[0], g["x"].shape[1], F_l, g["hidden"][l], direction=1,
+                                         flags=_lib.FLAG_SAVE_PREACT) == 2
+    x = _t(g["x"].astype(np.float32)).requires_grad_(True)
+    y = _t(g["labels"])
+    m.init_hidden()
+    if fused_head:
+        loss = m.loss(x, y)
+    else:
+        scores = m(x)
+        assert np.abs(scores.detach().cpu().numpy() - g["scores"]).max() <= 1e-5
+        loss = torch.nn.NLLLoss()(scores, y)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5
+    rel = lambda a, ref: float(np.abs(a.detach().cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    assert rel(x.grad, g["dx"]) <= 2e-5
+    assert rel(m.hidden2keyword.weight.grad, g["dfc_w"]) <= 2e-5 and rel(m.hidden2keyword.bias.grad, g["dfc_b"]) <= 2e-5
+    for rnn, (_, dp) in zip(m.rnn_list, g["layers"]):
+        for name, par in (("d_w", rnn.W), ("d_u", rnn.U), ("d_bias_gate", rnn.bias_gate), ("d_bias_update", rnn.bias_update),
+                          ("d_zeta", rnn.zeta), ("d_nu", rnn.nu)):
+            assert rel(par.grad, dp[name]) <= 2e-5, name
+
+
+def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
+    """B = 4096: loss, d_x and every parameter gradient of the 2-layer model against the fp64 oracle of the stack;
+    under no_grad the same scores come out of the inference path (top layer without its hidden-state sequence)."""
+    T, B, F, C = 99, 4096, 32, 12
+    hidden = [256, 128]
+    rng = np.random.default_rng(123)
+    layers = [O.make_params(F, 256, dtype=np.float32, seed=41, randomize_scalars=True),
+              O.make_params(256, 128, dtype=np.float32, seed=42, randomize_scalars=True)]
+    fc_w = (0.2 * rng.standard_normal((C, 128))).astype(np.float32)
+    fc_b = (0.1 * rng.standard_normal((C,))).astype(np.float32)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    y = rng.integers(0, C, (B,))
+    g = {"hidden": hidden, "x": x, "fc_w": fc_w, "fc_b": fc_b, "layers": [(p, None) for p in layers]}
+    m = _build_model(g)
+    xt = _t(x).requires_grad_(True)
+    loss = m.loss(xt, _t(y))
+    loss.backward()
+    torch.cuda.synchronize()
+    l64 = [{k: v.astype(np.float64) for k, v in p.items()} for p in layers]
+    loss_o, scores_o, h_last_o, dx_o, grads_o, dw_o, db_o = O.stack_forward_backward(
+        x.astype(np.float64), l64, fc_w.astype(np.float64), fc_b.astype(np.float64), y)
+    assert abs(float(loss) - float(loss_o)) <= 1e-5
+    rel = lambda a, ref: float(np.abs(a.detach().cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()) / max(1e-3, float(np.abs(ref).max()))
+    # the loss is a MEAN over 4096 utterances: gradients are ~1e-4 in size, so they are compared relative to their
+    # own largest element (floor 1e-3), at the 2e-5 the single layers meet
+    assert rel(xt.grad, dx_o) <= 5e-5
+    assert rel(m.hidden2keyword.weight.grad, dw_o) <= 2e-5 and rel(m.hidden2keyword.bias.grad, db_o) <= 2e-5
+    for rnn, go in zip(m.rnn_list, grads_o):
+        for name, par in (("d_w", rnn.W), ("d_u", rnn.U), ("d_bias_gate", rnn.bias_gate), ("d_bias_update", rnn.bias_update),
+                          ("d_zeta", rnn.zeta), ("d_nu", rnn.nu)):
+            assert rel(par.grad, go[name]) <= 5e-5, (name, rel(par.grad, go[name]))
+    with torch.no_grad():
+        m.init_hidden()
+        scores = m(_t(x))
+    assert np.abs(scores.cpu().numpy() - scores_o).max() <= 1e-5
