@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
 
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 sbz[2] = {z4, z4}, sbh[2] = {z4, z4}, dh[2] = {z4, z4};
-  float pz = 0.f, pn = 0.f;
+  float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;   // d_zeta / d_nu partial sums, compensated
 
   // Addresses: a wave-uniform step base (scalar registers) + a 32-bit lane offset (the host rejects B*H*4 >= 2^31)
   const unsigned lane_c = ((unsigned)bc * H2 + n0) * 4u, lane_v = ((unsigned)b * H2 + n0) * 4u;   // BYTE offsets
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
     // ---- EW(t): .cu:107-117 ---------------------------------------------------------------------------------
     f32x4 dpv[2];
-    float amax = 0.f;
+    float amax = 0.f, sn8 = 0.f, sz8 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       f32x4 bzq = z4, bhq = z4;
@@ -470,12 +470,13 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
         const float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;       // .cu:110
         const float cg = c * gg;
         sbz[mt][r] += dzp; sbh[mt][r] += dcp;
-        pn += cg; pz += cg - z * cg;                                             // .cu:114-115
+        sn8 += cg; sz8 += cg - z * cg;                                           // .cu:114-115
         dpv[mt][r] = dzp + dcp;                                                  // .cu:113
         dh[mt][r] = z * gg;                                                      // .cu:108: C-in of the chain
         amax = fmaxf(amax, fabsf(dpv[mt][r]));
       }
     }
+    kahan_add(pn, pn_c, sn8); kahan_add(pz, pz_c, sz8);
     if (valid) {                                     // d_pre_t for the weight-gradient / d_x GEMMs
       float* o = dpre_ws + (size_t)t * B * H2;
 #pragma unroll

@@ -749,7 +749,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     WTf = split3(lo, hi);
   }
   f32x4 sbz = f32x4{0.f, 0.f, 0.f, 0.f}, sbh = sbz, dh = sbz;
-  float pz = 0.f, pn = 0.f;
+  float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;     // d_zeta / d_nu partial sums, compensated
   auto role_body = [&](auto role_tag) __attribute__((always_inline)) {
   // dW / dU accumulators: row tiles 2rp + a, column tiles 5ch + c  (column tile 0,1 = dW, 2..9 = dU)
   const int rp = wv & 3;
@@ -847,16 +847,20 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   // value of x_t.  Leaves dh = z*g, the C-in of chain(t).
   auto ew_post = [&](int t, const EwOps& e, const EwPre& f, const f32x4 ggv) __attribute__((always_inline)) {
     f32x4 dpv;
+    float sn4 = 0.f, sz4 = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float gg = ggv[r];                                         // grad + d_old_h  (.cu:474)
       const float dcp = f.kc[r] * gg, dzp = f.kz[r] * gg;
       sbz[r] += dzp; sbh[r] += dcp;
       const float cg = f.c[r] * gg;
-      pn += cg; pz += cg - f.z[r] * cg;                                // .cu:114-115
+      sn4 += cg; sz4 += cg - f.z[r] * cg;                              // .cu:114-115
       dpv[r] = dzp + dcp;                                              // .cu:113
       dh[r] = f.z[r] * gg;                                             // .cu:108
     }
+    // compensated only where registers are to spare (the F = 32 build of this kernel has none: there the plain sum,
+    // 1.2e-5 of the result at B = 4096, stays)
+    if constexpr (NOX) { kahan_add(pn, pn_c, sn4); kahan_add(pz, pz_c, sz4); } else { pn += sn4; pz += sz4; }
     unsigned char* im = &S.img[t & 3][0];
     put4(im + OFF_DP, PLANE_H, my_row_h, dpv);
     put4(im + OFF_HP, PLANE_H, my_row_h, e.h);
@@ -1257,7 +1261,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   f32x4 sbz[NT], sbh[NT], dh[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
-  float pz = 0.f, pn = 0.f;
+  float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;     // d_zeta / d_nu partial sums, compensated
 
   struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
   // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
@@ -1293,6 +1297,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     __builtin_amdgcn_sched_barrier(0);
     // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
     f32x4 dpv[NT];
+    float sz8 = 0.f, sn8 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
       const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 4 * mt]);
@@ -1306,11 +1311,12 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
         const float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;       // .cu:110
         const float zg = z * gg;                                                  // .cu:108
         const float tz = (1.0f - z) * c * gg, tn = c * gg;                        // .cu:114-115
-        sbz[mt][r] += dzp; sbh[mt][r] += dcp; pz += tz; pn += tn;
+        sbz[mt][r] += dzp; sbh[mt][r] += dcp; sz8 += tz; sn8 += tn;
         dpv[mt][r] = dzp + dcp;                                                   // .cu:113
         dh[mt][r] = zg;
       }
     }
+    kahan_add(pz, pz_c, sz8); kahan_add(pn, pn_c, sn8);
     if (valid) {
       float* o = dpre_ws + (size_t)t * B * H + lane_hs;
 #pragma unroll

@@ -43,6 +43,16 @@ template <int GATE> __device__ __forceinline__ float gate_dact(float y) {
   return 1.0f - y * y;
 }
 
+// compensated (Kahan) running sum: s += y with the rounding error of every addition carried in c.  Used for the two
+// scalar gradients d_zeta / d_nu, whose per-lane sums run over T * (elements per lane) terms of either sign: a plain
+// fp32 running sum is good to ~sqrt(n) * 6e-8 of the partial sum, which showed as 2.5e-5 of the result at B = 64.
+__device__ __forceinline__ void kahan_add(float& s, float& c, float y) {
+  const float yy = y - c;
+  const float t = s + yy;
+  c = (t - s) - yy;
+  s = t;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

