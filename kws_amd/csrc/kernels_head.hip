@@ -169,9 +169,9 @@ int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const v
   const size_t lds = head_lds_bytes(H, C);
   // > 64 KB of dynamic LDS needs the opt-in; the attribute is per device, so it is set before every launch
   // that needs it (no process-wide state: the library is re-entrant and device-agnostic)
-  if (lds > 64 * 1024)
+  if (lds > 64 * 1024)                              // (what this launch needs, not the CU's 160 KB: the kernel also has static LDS)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_xent_fwd_bwd),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(head_xent_fwd_bwd, dim3(nwg), dim3(HEAD_THREADS), lds, s, B, H, C, (const float*)h_last,
                      (const float*)fc_w, (const float*)fc_b, (const long long*)labels, (float*)logp,

@@ -730,9 +730,11 @@ int launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs
   const bool ragged = (d.B % 16) != 0;
   auto pick = [&](auto gate_c) __attribute__((always_inline)) {
     constexpr int G = decltype(gate_c)::value;
-    if constexpr (H == 128 && F == 64) {
-      // no ragged-batch instantiation for this shape: it needs more registers than a wave has and its spill
-      // reloads break the operand rule; mfma_supported() sends that case to the generic scan
+    if constexpr (H == 128) {
+      // no ragged-batch instantiation for H = 128: it needs more registers than a wave has (F = 64) or spills inside
+      // the loop (F = 32), and spill reloads are loads nobody placed (operand rule; tools/war_scan.py
+      // rejects both); mfma_supported() sends that case on -- in practice only under FASTGRNN_FLAG_FORCE_F32_MFMA,
+      // the split-precision kernels take these shapes first
       args(bwd_scan_mfma<H, F, G, false>);
     } else {
       if (ragged) args(bwd_scan_mfma<H, F, G, true>); else args(bwd_scan_mfma<H, F, G, false>);
@@ -755,7 +757,7 @@ bool shape_ok(int H, int F) { return (H == 128 && F == 32) || (H == 64 && F == 3
 }  // namespace
 
 bool mfma_supported(const fastgrnn_desc& d, int direction) {
-  if (direction == 1 && d.H == 128 && d.F == 64 && (d.B % 16) != 0) return false;   // see launch_bwd
+  if (direction == 1 && d.H == 128 && (d.B % 16) != 0) return false;   // see launch_bwd
   return d.dtype == FASTGRNN_F32 && d.w_rank == 0 && d.u_rank == 0 && d.update_nl == FASTGRNN_NL_TANH &&
          d.gate_nl >= FASTGRNN_NL_SIGMOID && d.gate_nl <= FASTGRNN_NL_TANH && shape_ok(d.H, d.F);
 }

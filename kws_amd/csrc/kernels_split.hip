@@ -777,29 +777,45 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   // grad_hs, aux0 (z or pre), aux1 (c), h_prev; one x value.  bf16 sequences stay RAW (packed) until they are
   // used an iteration later: unpacking at load time would make every request synchronous.
   struct EwOps { f32x4 g, a0, a1, h; float xv; uint2 graw, hraw; unsigned short xraw; };
+  // Addresses: a wave-uniform step base (scalar registers) + a 32-bit BYTE lane offset (global_load ... v_off, s[base]):
+  // one VGPR per stream instead of a 64-bit pointer pair and its per-step arithmetic.  split_supported() keeps the
+  // whole sequence tensor below 2^32 bytes for this.
+  constexpr unsigned ESZ = BF ? 2u : 4u;             // bytes per sequence element (x, hs, grad_hs)
+  const unsigned lane_e = (unsigned)bc * (unsigned)rsB * H + n0;          // element offset of this lane inside a step's rows
+  const unsigned lane_bh = (unsigned)bc * H + n0;                         // ... inside a [B,H] tensor
+  const unsigned lane_x = NOX ? 0u : (xbft ? ((unsigned)xbc * F + xf) * (unsigned)Tn : (unsigned)xbc * (unsigned)rsB * F + xf);
+  auto ldg4 = [](const void* base, unsigned byte_off) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  auto ldg2 = [](const void* base, unsigned byte_off) __attribute__((always_inline)) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t o = ((size_t)t * rsT + (size_t)bc * rsB) * H + n0;
-    e.a0 = ld4(aux0 + o);
-    if (!PREACT) e.a1 = ld4(aux1 + o);
-    const size_t ex = NOX ? 0 : (xbft ? ((size_t)xbc * F + xf) * Tn + t : ((size_t)t * rsT + (size_t)xbc * rsB) * F + xf);
-    const size_t og = g_last ? (size_t)bc * H + n0 : o;
+    const size_t step_h = (size_t)t * rsT * H;       // uniform: element offset of step t's rows
+    e.a0 = ldg4(aux0 + step_h, lane_e * 4u);
+    if (!PREACT) e.a1 = ldg4(aux1 + step_h, lane_e * 4u);
     const bool g_zero = g_last && t != Tn - 1;       // wave-uniform
+    const char* gbase = g_last ? reinterpret_cast<const char*>(ghs) : reinterpret_cast<const char*>(ghs) + step_h * ESZ;
+    const unsigned goff = (g_last ? lane_bh : lane_e) * ESZ;
+    const char* hbase = (t == 0) ? reinterpret_cast<const char*>(hs)
+                                 : reinterpret_cast<const char*>(hs) + (step_h - (size_t)rsT * H) * ESZ;   // .cu:478-481
+    const char* xbase = xbft ? reinterpret_cast<const char*>(x) + (size_t)t * ESZ
+                             : reinterpret_cast<const char*>(x) + (size_t)t * rsT * F * ESZ;
     if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
-      e.graw = g_zero ? uint2{0u, 0u} : *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(ghs) + og);
+      e.graw = g_zero ? uint2{0u, 0u} : ldg2(gbase, goff);
       if (RAGGED && !valid) e.graw = uint2{0u, 0u};
-      e.hraw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(hs) + (t == 0 ? o : o - (size_t)rsT * H));
+      e.hraw = ldg2(hbase, lane_e * ESZ);            // (t == 0: a dummy row of hs; h0 below is what EW(0) uses)
       // h_prev of step 0 is the fp32 h0: requested HERE, with the step's other operands (load_ew runs behind a
       // completion read), not in unpack_ew, which sits between the chain's MFMAs and the first read of their result
-      if (t == 0) e.h = ld4(h0 + (size_t)bc * H + n0);
-      if (!NOX) e.xraw = reinterpret_cast<const unsigned short*>(x)[ex];
+      if (t == 0) e.h = ldg4(h0, lane_bh * 4u);
+      if (!NOX) e.xraw = *reinterpret_cast<const unsigned short*>(xbase + lane_x * ESZ);
     } else {
-      const float* hprev = (t == 0) ? h0 + (size_t)bc * H + n0 : hs + o - (size_t)rsT * H;   // .cu:478-481
-      e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(ghs + og);
+      e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(gbase, goff);
       // Lanes beyond a ragged batch re-read the last utterance's (finite) rows with a ZERO gradient: with dh = 0
       // at the start, gg, d_pre and every sum they enter stay exactly zero for them -- nothing else to mask.
       if (RAGGED && !valid) e.g = f32x4{0.f, 0.f, 0.f, 0.f};
-      e.h = ld4(hprev);
-      if (!NOX) e.xv = x[ex];
+      e.h = (t == 0) ? ldg4(h0, lane_bh * 4u) : ldg4(hbase, lane_e * 4u);
+      if (!NOX) e.xv = *reinterpret_cast<const float*>(xbase + lane_x * 4u);
     }
   };
   auto unpack4 = [](const uint2 v) __attribute__((always_inline)) {
@@ -830,9 +846,9 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       } else {
         z = e.a0[r]; c = e.a1[r];
       }
-      const float kc = (sz * (1.0f - z) + sn) * (1.0f - c * c); // d_pre_c = kc * gg   (.cu:109)
-      const float kz = (e.h[r] - sz * c) * gate_dact<GATE>(z);  // d_pre_z = kz * gg   (.cu:110)
-      f.kc[r] = kc; f.kz[r] = kz; f.z[r] = z; f.c[r] = c;
+      f.kc[r] = (sz * (1.0f - z) + sn) * (1.0f - c * c);        // d_pre_c = kc * gg   (.cu:109)
+      f.kz[r] = (e.h[r] - sz * c) * gate_dact<GATE>(z);         // d_pre_z = kz * gg   (.cu:110)
+      f.z[r] = z; f.c[r] = c;
     }
   };
   // planes of 4 fp32 values -> 8 bytes per plane at byte offset off of the three planes of one image part
@@ -854,18 +870,19 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       const float dcp = f.kc[r] * gg, dzp = f.kz[r] * gg;
       sbz[r] += dzp; sbh[r] += dcp;
       const float cg = f.c[r] * gg;
-      sn4 += cg; sz4 += cg - f.z[r] * cg;                              // .cu:114-115
+      if constexpr (NOX) { sn4 += cg; sz4 += cg - f.z[r] * cg; }       // .cu:114-115
+      else { pn += cg; pz += cg - f.z[r] * cg; }
       dpv[r] = dzp + dcp;                                              // .cu:113
       dh[r] = f.z[r] * gg;                                             // .cu:108
     }
     // compensated only where registers are to spare (the F = 32 build of this kernel has none: there the plain sum,
     // 1.2e-5 of the result at B = 4096, stays)
-    if constexpr (NOX) { kahan_add(pn, pn_c, sn4); kahan_add(pz, pz_c, sz4); } else { pn += sn4; pz += sz4; }
+    if constexpr (NOX) { kahan_add(pn, pn_c, sn4); kahan_add(pz, pz_c, sz4); }
     unsigned char* im = &S.img[t & 3][0];
     put4(im + OFF_DP, PLANE_H, my_row_h, dpv);
     put4(im + OFF_HP, PLANE_H, my_row_h, e.h);
     if (NOX) {                                       // d_pre_t for the weight-gradient / d_x GEMMs (fp32, [T,B,H] layout of hs)
-      if (valid) st4(d_x + ((size_t)t * rsT + (size_t)b * rsB) * H + n0, dpv);
+      if (valid) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(d_x + (size_t)t * rsT * H) + ((unsigned)b * (unsigned)rsB * H + n0) * 4u) = dpv;
     } else {
       unsigned short s0, s1, s2;
       split_one(e.xv, s0, s1, s2);
@@ -887,8 +904,9 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
           }
         }
       } else {
-        const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * F + wv * 16 + 4 * g;
-        if (valid) { if (BF) st4_bf16(reinterpret_cast<unsigned short*>(d_x) + o, sacc); else st4(d_x + o, sacc); }
+        char* xo = reinterpret_cast<char*>(d_x) + (size_t)t * rsT * F * ESZ;                 // uniform step base
+        const unsigned lo = ((unsigned)b * (unsigned)rsB * F + wv * 16 + 4 * g) * ESZ;
+        if (valid) { if (BF) st4_bf16(xo + lo, sacc); else *reinterpret_cast<f32x4*>(xo + lo) = sacc; }
       }
     }
   };
@@ -934,14 +952,23 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       __builtin_amdgcn_sched_barrier(0);
     };
     // batches of 2 + 2 + 1 column tiles: with 3 + 2 the kernel spilled nine registers inside the loop
-    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-    batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-    if constexpr (NC == 5) batch(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+    // (the tanh gate recomputed from the pre-activation needs a few registers more around this phase: with
+    // two-tile batches it spilled the next step's operands inside the loop; one tile per batch there)
+    constexpr bool ONE_TILE_BATCHES = PREACT && GATE == FASTGRNN_NL_TANH && !NOX;
+    if constexpr (ONE_TILE_BATCHES) {
+      static_for<NC>([&](auto c_tag) __attribute__((always_inline)) { batch(c_tag, std::integral_constant<int, 1>{}); });
+    } else {
+      batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+      batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+      if constexpr (NC == 5) batch(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+    }
   };
 
   const int top = (Tn & 1) ? Tn : Tn - 1;          // highest (possibly virtual) step: pairs are (odd, even)
-  // One iteration.  eo = operands of EW(t-1) (requested an iteration ago); e_load receives those of EW(t-2).
-  auto iter = [&](auto last_tag, auto even_tag, int t, EwOps& eo, EwOps& e_load) __attribute__((always_inline)) {
+  // One iteration.  eo = operands of EW(t-1) (requested an iteration ago); once EW(t-1) has consumed them the same
+  // registers receive the requests for EW(t-2) (ONE operand set: two sets alternating over the unrolled loop cost
+  // the compiler ~40 registers more, i.e. spills inside the loop).
+  auto iter = [&](auto last_tag, auto even_tag, int t, EwOps& eo) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value, EVEN = decltype(even_tag)::value;
     SPLIT_STAMP(0)
     constexpr bool MY_TURN = EVEN ? (ch == 0) : (ch == 1);
@@ -966,6 +993,9 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) mfma6_hl(UTf[s2], dB[s2], dh, dlo);
       dh += dlo;
+      // this sum is the read that proves the chain has retired: pinned here (in the last iteration nothing else
+      // needs dh before the flush, and the optimiser would sink the add below the next fragment loads)
+      asm volatile("" : "+v"(dh));
       // (a runtime index would put the fragments in scratch.)  Every arm issues the product -- the last one
       // unconditionally: xks < KS -- and the partial is stored OUTSIDE the selection: that store is the read which
       // proves these MFMAs, the youngest of the step, have retired (tools/war_scan.py follows every feasible path).
@@ -992,7 +1022,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       ew_post(t - 1, eo, f, eo.g + dh);
       __builtin_amdgcn_sched_barrier(0);
       // requests for EW(t-2), after the chain has retired (they may land in registers its fragments used)
-      load_ew(t >= 2 ? t - 2 : 0, e_load);
+      load_ew(t >= 2 ? t - 2 : 0, eo);
     }
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(2)
@@ -1003,29 +1033,24 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     SPLIT_STAMP(4)
   };
 
-  EwOps E0, E1;                                     // operands of EW(s) for even / odd s
+  EwOps E;
   __syncthreads();                                  // bias staged, virtual-step images zeroed
   {
     EwPre f;
-    if ((Tn - 1) & 1) {
-      load_ew(Tn - 1, E1);
-      if (Tn >= 2) load_ew(Tn - 2, E0);
-      unpack_ew(Tn - 1, E1); ew_pre(E1, f); ew_post(Tn - 1, E1, f, E1.g);
-    } else {
-      load_ew(Tn - 1, E0);
-      if (Tn >= 2) load_ew(Tn - 2, E1);
-      unpack_ew(Tn - 1, E0); ew_pre(E0, f); ew_post(Tn - 1, E0, f, E0.g);
-    }
+    load_ew(Tn - 1, E);
+    unpack_ew(Tn - 1, E); ew_pre(E, f); ew_post(Tn - 1, E, f, E.g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (Tn >= 2) load_ew(Tn - 2, E);
   }
   __syncthreads();
   {
     int t = Tn - 1;
-    if (t & 1) { iter(std::false_type{}, std::false_type{}, t, E0, E1); --t; }
+    if (t & 1) { iter(std::false_type{}, std::false_type{}, t, E); --t; }
     for (; t >= 2; t -= 2) {
-      iter(std::false_type{}, std::true_type{}, t, E1, E0);
-      iter(std::false_type{}, std::false_type{}, t - 1, E0, E1);
+      iter(std::false_type{}, std::true_type{}, t, E);
+      iter(std::false_type{}, std::false_type{}, t - 1, E);
     }
-    iter(std::true_type{}, std::true_type{}, 0, E1, E0);
+    iter(std::true_type{}, std::true_type{}, 0, E);
   }
 #ifdef FASTGRNN_DIAG_STAMPS
   if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
@@ -1118,7 +1143,8 @@ __global__ __launch_bounds__(1024) void reduce_slabs_split(int nwg, const float*
 // Dense H = 128 layers whose input is not 32 wide (F = 64 / 128 / 256: the reference's second layer, model.py:196-203):
 // the scans keep the recurrence only, the frame products are batched GEMMs (kernels_gemm.hip).
 bool dense_wide_shape(const fastgrnn_desc& d) {
-  return d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && (d.F == 64 || d.F == 128 || d.F == 256);
+  return d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && (d.F == 64 || d.F == 128 || d.F == 256) &&
+         (double)d.T * d.B * d.F * 4.0 < 4294967296.0;       // 32-bit byte offsets inside a tensor (see split_supported)
 }
 struct WideBwdWs { size_t slabs, dpre, tn, total; };
 WideBwdWs wide_bwd_layout(const fastgrnn_desc& d) {
@@ -1282,7 +1308,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     }
   };
 
-  auto step = [&](int t, const EwOps& e, EwOps& e_load) __attribute__((always_inline)) {
+  auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const int cur = t & 1;
     {
       // dh read = the previous step's MFMAs have retired: the requests below may land in registers they read
@@ -1293,8 +1319,6 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       if (touch == 1.2345678e38f) red[0] = 1.f;
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t > 0) load_ew(t - 1, e_load);
-    __builtin_amdgcn_sched_barrier(0);
     // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
     f32x4 dpv[NT];
     float sz8 = 0.f, sn8 = 0.f;
@@ -1317,6 +1341,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       }
     }
     kahan_add(pz, pz_c, sz8); kahan_add(pn, pn_c, sn8);
+    // EW(t) has consumed the operand set (and read dh: the previous step's MFMAs have retired): refill it for t-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (t > 0) load_ew(t - 1, e);
+    __builtin_amdgcn_sched_barrier(0);
     if (valid) {
       float* o = dpre_ws + (size_t)t * B * H + lane_hs;
 #pragma unroll
@@ -1365,15 +1393,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
   };
 
-  EwOps ea, eb;
+  EwOps ea;                                          // ONE operand set, refilled right behind its use (see step)
   __syncthreads();                                   // sbias
   load_ew(Tn - 1, ea);
-  int t = Tn - 1;
-  for (; t >= 1; t -= 2) {
-    step(t, ea, eb);
-    step(t - 1, eb, ea);
-  }
-  if (t == 0) step(0, ea, eb);
+  for (int t = Tn - 1; t >= 0; --t) step(t, ea);
   {
     // the last step's MFMAs have retired before anything below (stores masked by `valid`, the reductions' LDS
     // traffic) may reuse their operand registers: an unconditional read of every d_h accumulator
@@ -1770,7 +1793,10 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   if ((d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO) || d.update_nl != FASTGRNN_NL_TANH ||
       d.gate_nl < FASTGRNN_NL_SIGMOID || d.gate_nl > FASTGRNN_NL_QUANT_SIGM4)
     return false;
-  const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32;
+  // the 8-wave scans address a step's rows with 32-bit byte offsets from a scalar base: whole sequence tensors
+  // below 2^32 bytes (B = 4096, T = 99, H = 128 is 2e8; anything larger goes to the other paths)
+  const bool fits32 = (double)d.T * d.B * (d.H > d.F ? d.H : d.F) * 4.0 < 4294967296.0;
+  const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32 && fits32;
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (h256_shape(d)) return h256_supported(d, direction);      // dense H = 256 / F = 32: kernels_h256.hip
   // dense H = 128 with a wider input (F = 64 / 128 / 256; the reference's second layer): recurrence-only scans +

@@ -127,6 +127,27 @@ def parse_kernel(lines):
     return ins, set(labels.values())
 
 
+def scratch_in_loops(lines):
+    """Spill traffic inside a loop: (label, instruction) pairs for every scratch_* instruction that sits between a
+    label and a later branch back to it.  The scans are written to run without spills (a spill reload is a load the
+    author never placed, and the one build of the 8-wave backward that spilled inside its loop was the one that gave
+    run-to-run differences on the GPU: DESIGN.md 4.0)."""
+    pos, out = {}, []
+    texts = []
+    for lab, text in lines:
+        if lab is not None:
+            pos[lab] = len(texts)
+        else:
+            texts.append(text)
+    for j, text in enumerate(texts):
+        m = re.match(r"s_c?branch\w*\s+(\.L\w+)", text)
+        if m and m.group(1) in pos and pos[m.group(1)] <= j:
+            for k in range(pos[m.group(1)], j):
+                if texts[k].startswith("scratch_"):
+                    out.append((m.group(1), texts[k]))
+    return sorted(set(out))
+
+
 def track_scalars(x, known):
     """apply instruction x to the dict of known scalar flags (see parse_kernel)"""
     if not x.sdst:
@@ -272,6 +293,7 @@ for name, lines in kernels.items():
     ins, block_starts = parse_kernel(lines)
     TRACE_ON[0] = bool(TRACE) and TRACE in name
     n_mfma, hits, unbounded = scan_kernel(ins, block_starts)
+    spills = scratch_in_loops(lines) if n_mfma else []
     if True:
         short = re.sub(r"^_ZN8fastgrnn12_GLOBAL__N_1\d+", "", name)[:48]
         print("%-50s mfma %4d  load-behind-mfma pairs %3d%s%s" % (
@@ -279,7 +301,9 @@ for name, lines in kernels.items():
             ("   UNBOUNDED paths %d" % unbounded) if unbounded else ""))
         for h in sorted(hits)[:3]:
             print("      +%d  %s   <-   %s" % h)
-        bad_total += len(hits) + unbounded
+        if spills:
+            print("      SPILLS IN LOOP %d, e.g. %s: %s" % (len(spills), spills[0][0], spills[0][1]))
+        bad_total += len(hits) + unbounded + (1 if spills else 0)
 missing = sorted(declared - set(kernels))
 print("kernels declared %d, scanned %d%s" % (len(declared), len(kernels), (", NOT SCANNED: " + " ".join(missing)) if missing else ""))
 if missing:
