@@ -487,11 +487,12 @@ def test_run_to_run_bitwise_repeatability():
     on the same inputs must agree bit for bit.  A difference means an on-chip race -- e.g. a load
     landing in a register that an in-flight MFMA still reads (seen while prototyping a two-role
     backward)."""
-    T, F = 99, 32
-    # (H, rank, B, flags): 8-wave kernels under both saved-tensor contracts, the low-rank pair, the 4-wave
-    # forward (8) and the fp32-MFMA path (2)
-    for (H, r, B, flags) in ((128, 0, 1024, 4), (256, 16, 512, 4), (128, 0, 1008, 0), (128, 0, 1024, 4 | 8),
-                             (128, 0, 512, 2), (256, 16, 512, 0)):
+    T = 99
+    # (H, rank, B, flags, F): 8-wave kernels under both saved-tensor contracts, the low-rank pair, the 4-wave
+    # forward (8), the fp32-MFMA path (2), the headline batch, and the stack's layers (wide input; H = 256)
+    for (H, r, B, flags, F) in ((128, 0, 1024, 4, 32), (256, 16, 512, 4, 32), (128, 0, 1008, 0, 32), (128, 0, 1024, 4 | 8, 32),
+                                (128, 0, 512, 2, 32), (256, 16, 512, 0, 32), (128, 0, 4096, 4, 32), (128, 0, 1024, 4, 256),
+                                (256, 0, 1024, 4, 32), (256, 0, 1000, 0, 32)):
         p = O.make_params(F, H, r or None, r or None, seed=21)
         P = _param_tensors(p)
         g = torch.Generator().manual_seed(3)
@@ -511,7 +512,7 @@ def test_run_to_run_bitwise_repeatability():
                 first = [o.clone() for o in allo]
             else:
                 for k, (a, b) in enumerate(zip(allo, first)):
-                    assert torch.equal(a, b), (H, r, flags, rep, k)
+                    assert torch.equal(a, b), (H, F, r, B, flags, rep, k)
 
 
 @pytest.mark.parametrize("B,preact", [(37, True), (64, True), (48, False), (1, True)])
