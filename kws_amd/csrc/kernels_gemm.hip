@@ -179,7 +179,7 @@ void launch_rows_gemm(size_t R, const void* A, const float* W, void* C, bool bf_
 // ------------------------------------------------------------------------------------------
 // C[M,N] = A[R,M]^T . B[R,N]   (M = 128 per workgroup row block, N = 16 * NT <= 256)
 // ------------------------------------------------------------------------------------------
-// Workgroup = 8 waves = one chunk of rows x one 128-column block of A (grid.y).  Stages of 32 rows (one MFMA
+// Workgroup = 8 waves = one chunk of rows x one 128-column block of A.  Stages of 32 rows (one MFMA
 // K-step): global fp32 -> three exact bf16 planes in LDS in natural [row][column] order (double-buffered, the
 // next stage's loads in flight under the MFMAs) -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs
 // into register accumulators.  Wave w owns m-tiles 2(w&3), 2(w&3)+1 of the block and n-tiles (w>>2)*NT/2 ...:
@@ -189,7 +189,7 @@ void launch_rows_gemm(size_t R, const void* A, const float* W, void* C, bool bf_
 constexpr int TNB_STAGE = 32;
 
 template <int NT>
-__global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B0, const float* __restrict__ B1,
                                                    size_t shiftB, int ldb, float* __restrict__ part) {
   constexpr int MB = 128, N = 16 * NT, NH = NT / 2, NBATCH = NH < 4 ? NH : 4;
@@ -203,9 +203,12 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
   const int mq = wv & 3, nh = wv >> 2;
-  const int mblk = blockIdx.y;                     // 128-column block of A
+  // consecutive workgroups take the column blocks of ONE row chunk: they run at the same time and read the same rows
+  // of B, so the second read comes from the Infinity Cache instead of HBM
+  const int mblk = blockIdx.x % nblk;              // 128-column block of A
+  const int chunk = blockIdx.x / nblk;
   const size_t nstages = (R + TNB_STAGE - 1) / TNB_STAGE;
-  const size_t s_begin = (size_t)blockIdx.x * stages_per_wg;
+  const size_t s_begin = (size_t)chunk * stages_per_wg;
   const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
 
   f32x4 va[VA], vb[VB];
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     }
   }
   // D row 4g + r of tile (mt, nt) is m = 16 mt + 4g + r, column n = 16 nt + (l & 15)
-  float* pc = part + ((size_t)blockIdx.x * gridDim.y + mblk) * MB * N;
+  float* pc = part + ((size_t)chunk * nblk + mblk) * MB * N;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -385,9 +388,9 @@ int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float
   if (!tn_gemm_big_supported(M, N)) return FASTGRNN_ERR_UNSUPPORTED;
   int spw;
   const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
-  dim3 grid(nch, nblk);
+  dim3 grid(nch * nblk);
 #define TNB_CASE(n) \
-  if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, A, lda, B0, B1, shiftB, ldb, part);
+  if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, nblk, A, lda, B0, B1, shiftB, ldb, part);
   TNB_CASE(32) TNB_CASE(64) TNB_CASE(128) TNB_CASE(256)
 #undef TNB_CASE
   const int total = M * N;

@@ -1,4 +1,4 @@
-"""Data-parallel path (kws_amd/dp.py) on CPU with gloo, world_size 2.
+"""Data-parallel path (kws_amd/dp.py) on CPU with gloo, world_size 2 and 8.
 
 The DP harness is backend-agnostic host logic (sharding, one flattened bucket, one
 all-reduce, unflatten); on the GPU box the same code runs over RCCL.  The compute
@@ -97,6 +97,69 @@ def test_dp_two_ranks_matches_single_process(lowrank, ragged):
     F, H = 5, 12
     expect = (3 * (F + H) + 2 * 3 * H + 2 * H + 2) if lowrank else (H * F + H * H + 2 * H + 2)
     assert res[0][2] == expect
+
+
+def _worker8(rank, world, port, q):
+    """world size 8, ragged shards (B = 32768 + 5: the first five ranks hold one utterance more), the sum identity
+    against a single-process run (rank 0 only), then both bucket paths under a real collective: gradients that alias
+    one flat buffer (zero-copy) and the pack -> all-reduce -> unpack fallback."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kws_amd.dp import GradBucket, data_parallel_step, shard_batch, shard_range
+        torch.set_num_threads(1)
+        T, B, F, H = 4, 32768 + 5, 5, 12
+        torch.manual_seed(0)
+        model = _PortModule(F, H).double()
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(T, B, F, generator=g, dtype=torch.float64)
+        G = torch.randn(T, B, H, generator=g, dtype=torch.float64)
+        params = list(model.parameters())
+        lo, hi = shard_range(B, rank, world)
+        ok = (hi - lo) == (4097 if rank < 5 else 4096)
+        bucket = GradBucket(params, world, divisor=1)
+        data_parallel_step(model, shard_batch(x, rank, world), shard_batch(G, rank, world), bucket)
+        dp_grads = [p.grad.clone() for p in params]
+        if rank == 0:                                  # the whole batch in one process
+            for p in params:
+                p.grad = None
+            model(x).backward(G)
+            for a, p in zip(dp_grads, params):
+                ok = ok and torch.allclose(a, p.grad, rtol=1e-9, atol=1e-10)
+        # zero-copy path: the gradients are views of one flat buffer, in parameter order
+        sizes = [p.numel() for p in params]
+        flat = torch.full((sum(sizes),), float(rank + 1), dtype=torch.float64)
+        for p, v in zip(params, flat.split(sizes)):
+            p.grad = v.view_as(p)
+        b2 = GradBucket(params, world)                 # mean over ranks
+        out = b2.all_reduce_()
+        ok = ok and out.data_ptr() == flat.data_ptr() and torch.allclose(flat, torch.full_like(flat, 4.5))
+        # fallback: one gradient lives elsewhere -> pack, collective, unpack
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        ok = ok and b2.shared_flat_() is None
+        out = b2.all_reduce_()
+        ok = ok and out.data_ptr() == b2.flat.data_ptr()
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 4.5)) for p in params)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_eight_ranks_ragged_shards_and_both_bucket_paths():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(8)) and all(ok for _, ok in res), res
 
 
 def test_shard_range_covers_everything():

@@ -49,10 +49,11 @@ def test_relu_gate_state_beyond_fp16_range_matches_oracle():
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     hs_o, _, _ = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate="relu")
     assert np.abs(hs_o).max() > 1e5 and np.isfinite(hs).all()
-    # A gate above 1 is not contractive: rounding differences are amplified frame over frame, for ANY fp32 evaluation.
-    # The yardstick is therefore the oracle itself run in fp32 (numpy): the kernel must be as close to fp64 as that.
+    # Error relative to the largest state of the same utterance and frame (single elements pass through zero while
+    # their neighbours are at 1e6: what a consumer of h_t -- a dot product -- sees is the error against the row's
+    # scale), and judged beside the oracle itself run in fp32 (numpy), since a gate above 1 is not contractive.
     hs_32, _, _ = O.unroll_forward(x, p, h0, gate="relu")
-    rel = lambda a: float((np.abs(a - hs_o) / np.maximum(1.0, np.abs(hs_o))).max())
+    rel = lambda a: float((np.abs(a - hs_o) / np.maximum(1.0, np.abs(hs_o).max(axis=2, keepdims=True))).max())
     assert rel(hs) <= max(1e-5, 3.0 * rel(hs_32)), (rel(hs), rel(hs_32))
 
 
