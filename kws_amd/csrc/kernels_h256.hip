@@ -199,6 +199,131 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     }
   };
 
+  if constexpr (H16) {
+  // ---- fp16 path: software-pipelined step (tools/diag_h256.hip showed the first build spending 350 cycles per
+  // fragment batch on exposed LDS latency and pipe drains, with the SIMD's second wave queued behind all of it):
+  //   * the frame product W.x_{t+1} is issued at the END of step t, between publishing h_t and the barrier -- it
+  //     does not depend on h, so it fills the barrier wait instead of opening the next step;
+  //   * the state product walks the K-steps with two operand sets and two accumulator sets: while K-step k's MFMAs
+  //     execute, K-step k-1's accumulators are read (completion) and its set is refilled for K-step k+1.
+  __syncthreads();                                   // sbias staged, W planes written
+  publish_h(0);
+  publish_x(0, load_x(0));
+  if (Tn > 1) publish_x(1, load_x(1));
+  float xnext = load_x(Tn > 2 ? 2 : Tn - 1);         // frame t+2, published during step t
+  __syncthreads();
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 wxa[2], wxl[2];                              // W.x of the coming step: big / small terms
+  auto wx_issue = [&](int buf) __attribute__((always_inline)) {
+    Frag3 xB, Wl[2];
+    const unsigned char* xp = xpl + buf * 3 * PLX2;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(xp + p * PLX2 + i * ROWX2 + 16 * g);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Wl[mt].p[p] = wfl[((wv * 2 + mt) * 3 + p) * 64 + l];
+    __builtin_amdgcn_sched_barrier(0);               // every fragment read issued before the first MFMA
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { wxa[mt] = z4; wxl[mt] = z4; mfma6_hl(Wl[mt], xB, wxa[mt], wxl[mt]); }   // .cu:356
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  wx_issue(0);
+  lds_barrier();                                     // every wave has read frame 0's planes: buffer 0 may take frame 2
+
+  f32x4 aux_prev[2] = {z4, z4};
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
+  struct KOps { u32x4 hi, lo; };
+  for (int t = 0; t < Tn; ++t) {
+    SPLIT_STAMP(0)
+    const int cur = t & 1, nxt = cur ^ 1;
+    const unsigned char* hp = hpl + cur * NPL * PLH2;
+    // W.x_t was issued before the barrier: reading its accumulators proves it has retired before any request below
+    // may reuse its operand registers
+    f32x4 wx[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) wx[mt] = wxa[mt] + wxl[mt];
+    asm volatile("" : "+v"(wx[0]), "+v"(wx[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    const float xpub = xnext;
+    xnext = load_x(t + 3 < Tn ? t + 3 : Tn - 1);
+    auto req = [&](int k, KOps& o) __attribute__((always_inline)) {
+      const unsigned off = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
+      o.hi = *reinterpret_cast<const u32x4*>(hp + off);
+      o.lo = *reinterpret_cast<const u32x4*>(hp + PLH2 + off);
+    };
+    KOps o0, o1;
+    f32x4 ah[2][2] = {{z4, z4}, {z4, z4}}, al[2][2] = {{z4, z4}, {z4, z4}};     // [set][tile]: U.h scaled by 2^k
+    req(0, o0);
+    req(1, o1);
+    if (t > 0) store_step(t - 1, aux_prev);          // h_{t-1} (+ its pre-activation): issued during the LDS round trip
+    if (t + 2 < Tn) publish_x(cur, xpub);            // frame t+2 (buffer `cur` held frame t, last read before the barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
+    static_for<KS2>([&](auto k_tag) __attribute__((always_inline)) {
+      constexpr int k = decltype(k_tag)::value;
+      constexpr int st = k & 1;
+      {
+        const KOps& o = st ? o1 : o0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {                                                 // .cu:368, scaled by 2^k
+          al[st][mt] = mfma_f16(Uh[mt][k].lo, o.hi, al[st][mt]);
+          al[st][mt] = mfma_f16(Uh[mt][k].hi, o.lo, al[st][mt]);
+          ah[st][mt] = mfma_f16(Uh[mt][k].hi, o.hi, ah[st][mt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k >= 1 && k + 1 < KS2) {
+        // K-step k-1 has retired once its accumulators can be read; its operand set is then free for K-step k+1
+        constexpr int pv = st ^ 1;
+        float touch = ah[pv][0][0] + ah[pv][1][0] + al[pv][0][0] + al[pv][1][0];
+        if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
+        // the set's registers stay allocated up to here (the compiler considers an operand dead once its MFMAs have
+        // ISSUED and would hand its registers to the next request at once)
+        if constexpr (pv) asm volatile("" :: "v"(o1.hi), "v"(o1.lo)); else asm volatile("" :: "v"(o0.hi), "v"(o0.lo));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (pv) req(k + 1, o1); else req(k + 1, o0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    SPLIT_STAMP(2)
+    // ---- epilogue: .cu:55-58 (reading every accumulator: the step's MFMAs have retired) ------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 pre = wx[mt] + ((ah[0][mt] + ah[1][mt]) + (al[0][mt] + al[1][mt])) * u_unscale;
+      const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 16 * mt]);
+      const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 16 * mt]);
+      f32x4 zq, cq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = gate_act<GATE>(pre[r] + bzq[r]);
+        const float c = ftanh(pre[r] + bhq[r]);
+        hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
+        zq[r] = z; cq[r] = c;
+      }
+      if (AUX == 1 && valid) {                       // reference operator outputs: stored at once
+        const size_t o = (size_t)t * B * H2 + lane_hs + 16 * mt;
+        st4(zs + o, zq); st4(cs + o, cq);
+      }
+      aux_prev[mt] = pre;
+    }
+    asm volatile("" :: "v"(o0.hi), "v"(o0.lo), "v"(o1.hi), "v"(o1.lo));      // (both sets: allocated until the reads above)
+    SPLIT_STAMP(3)
+    publish_h(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < Tn) wx_issue(nxt);                   // W.x_{t+1}: frame t+1's planes were published a step ago
+    SPLIT_STAMP(4)
+    lds_barrier();
+    SPLIT_STAMP(5)
+  }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
+#endif
+  store_step(Tn - 1, aux_prev);
+  } else {
   __syncthreads();                                   // sbias staged; bf16 path: every wave's plane-2 fragments written
   publish_h(0);
   publish_x(0, load_x(0));
@@ -206,7 +331,12 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
   __syncthreads();
 
   f32x4 aux_prev[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   for (int t = 0; t < Tn; ++t) {
+    SPLIT_STAMP(0)
     const int cur = H16 ? (t & 1) : 0, nxt = H16 ? (cur ^ 1) : 0;
     const float xpub = xnext;
     xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
@@ -245,6 +375,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    SPLIT_STAMP(1)
 #pragma unroll
     for (int k0 = 0; k0 < KS2; k0 += KB) {
       Frag2h hH[KB];
@@ -286,6 +417,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
       __builtin_amdgcn_sched_barrier(0);
     }
+    SPLIT_STAMP(2)
     // ---- epilogue: .cu:55-58 -----------------------------------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -306,14 +438,21 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       }
       aux_prev[mt] = pre;
     }
+    SPLIT_STAMP(3)
     if (!H16) {                                      // single-buffered planes: everyone has read h_{t-1}, x_t by now
       lds_barrier();
       publish_x(0, xpub);
     }
     publish_h(nxt);
+    SPLIT_STAMP(4)
     lds_barrier();
+    SPLIT_STAMP(5)
   }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
+#endif
   store_step(Tn - 1, aux_prev);
+  }
   {                                                  // the weight fragments stay allocated through the last step
     float probe = hown[0][0];
 #pragma unroll
@@ -445,7 +584,12 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
 
   // ONE operand set: EW(t) consumes it at the top of the step and the requests for EW(t-1) refill it right behind
   // the step's LDS hand-off (two sets and a loop unrolled by two cost ~40 registers more and spilled)
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    SPLIT_STAMP(0)
     // ---- EW(t): .cu:107-117 ---------------------------------------------------------------------------------
     f32x4 dpv[2];
     float amax = 0.f, sn8 = 0.f, sz8 = 0.f;
@@ -489,7 +633,9 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);       // amax = f * 2^ex, f in [0.5, 1)
     ex = ex < -112 ? -112 : ex;                      // (2^(12-ex) must stay a normal float)
     const float dscale = ldexpf(1.0f, 12 - ex);
+    SPLIT_STAMP(1)
     lds_barrier();                                   // every wave has finished reading the planes of step t+1
+    SPLIT_STAMP(2)
     if (g == 0) sinv[i][wv] = ldexpf(u_unscale, ex - 12);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -500,47 +646,73 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       *reinterpret_cast<uint2*>(dpl + off) = hi;
       *reinterpret_cast<uint2*>(dpl + PLH2 + off) = lo;
     }
+    SPLIT_STAMP(3)
     lds_barrier();
+    SPLIT_STAMP(4)
     // requests for EW(t-1): behind the reads of dh above (they may land in registers the last chain's fragments used)
     if (t > 0) load_ew(t - 1, e);
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain(t): d_h = z*g + U^T d_pre_t (.cu:537): per K-step three fp16 MFMAs per row tile into a fresh
     //      accumulator, un-scaled into dh by one fma per result -----------------------------------------------------
+    // Software pipeline over the K-steps, two operand sets: while the three MFMAs per tile of K-step k execute, the
+    // partial products of K-step k-1 are folded into dh (that read also proves K-step k-1 has retired) and the
+    // fragments of K-step k+1 are requested into the set K-step k-1 used.  Taking one K-step at a time and waiting
+    // for its MFMAs before the next request cost 350 cycles per K-step (tools/diag_h256.hip), most of it exposed LDS
+    // latency and pipe drain -- and the SIMD's second wave queues behind all of it.
+    struct KOps { Frag2h dB; u32x4 Ul[2]; float inv; };
+    auto req = [&](int k, KOps& o) __attribute__((always_inline)) {
+      const unsigned off = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
+      o.dB.hi = *reinterpret_cast<const u32x4*>(dpl + off);
+      o.dB.lo = *reinterpret_cast<const u32x4*>(dpl + PLH2 + off);
 #pragma unroll
-    for (int k = 0; k < KS2; ++k) {                  // one K-step per fragment batch
-      Frag2h dB;
-      u32x4 Ul[2];
-      const unsigned o = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
-      dB.hi = *reinterpret_cast<const u32x4*>(dpl + o);
-      dB.lo = *reinterpret_cast<const u32x4*>(dpl + PLH2 + o);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
-      const float inv = sinv[i][k];
-      __builtin_amdgcn_sched_barrier(0);             // all fragment reads of the batch issued before its first MFMA
-      f32x4 pr[2];
+      for (int mt = 0; mt < 2; ++mt) o.Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
+      o.inv = sinv[i][k];
+    };
+    auto issue = [&](int k, const KOps& o, f32x4* pr) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        f32x4 a = mfma_f16(Ul[mt], dB.hi, z4);                       // small terms first
-        a = mfma_f16(UTh[mt][k], dB.lo, a);
-        pr[mt] = mfma_f16(UTh[mt][k], dB.hi, a);
+        f32x4 a = mfma_f16(o.Ul[mt], o.dB.hi, z4);                   // small terms first
+        a = mfma_f16(UTh[mt][k], o.dB.lo, a);
+        pr[mt] = mfma_f16(UTh[mt][k], o.dB.hi, a);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // reading the partial products retires the batch before its registers are reloaded (operand rule)
+    };
+    auto fold = [&](const KOps& o, const f32x4* pr) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r], inv, dh[mt][r]);
-      // (pinned here: without a use at this point the optimiser sinks the fmas below the next batches' reads and
-      // the completion read with them)
-      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]));
+        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r], o.inv, dh[mt][r]);
+      // (pinned: without a use here the optimiser sinks the fmas below later requests, and the completion read with
+      // them; the operand set stays allocated up to here -- the compiler considers it dead once its MFMAs have ISSUED)
+      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]) : "v"(o.dB.hi), "v"(o.dB.lo), "v"(o.Ul[0]), "v"(o.Ul[1]));
+    };
+    KOps o0, o1;
+    f32x4 p0[2], p1[2];
+    req(0, o0);
+    req(1, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<KS2>([&](auto k_tag) __attribute__((always_inline)) {
+      constexpr int k = decltype(k_tag)::value;
+      if constexpr ((k & 1) == 0) issue(k, o0, p0); else issue(k, o1, p1);
       __builtin_amdgcn_sched_barrier(0);
-    }
+      if constexpr (k >= 1) {
+        // K-step k-1: fold (completion read), then its operand set is free for K-step k+1
+        if constexpr ((k & 1) == 0) { fold(o1, p1); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o1); }
+        else                        { fold(o0, p0); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o0); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    fold(o1, p1);                                    // K-step 7
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   EwOps ea;
   __syncthreads();                                   // sbias, lo-plane fragments
   load_ew(Tn - 1, ea);
   for (int t = Tn - 1; t >= 0; --t) step(t, ea);
+#ifdef FASTGRNN_DIAG_STAMPS
+  { SPLIT_STAMP(5) }
+  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
+#endif
   // ---- flush ---------------------------------------------------------------------------------
   if (valid) {
 #pragma unroll
