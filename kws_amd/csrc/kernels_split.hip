@@ -227,7 +227,10 @@ constexpr int W8_ROWX = 80;             // bytes per utterance row of a 32-wide 
 // and enters each step as the C-in of the state product.  P is read through the pointer the step's fp32 auxiliary
 // output goes to -- zs (AUX 0 / 2 / 3: the pre-activation overwrites it in place under AUX == 2) or cs (AUX == 1: c
 // overwrites it) -- so no two restrict-qualified pointers alias.  x, w are unused.
-template <int GATE, int AUX, bool RAGGED, bool BF = false, bool F16H = true, bool PREIN = false>
+// UQ: the update nonlinearity is quantTanh = clip(a, -1, 1) instead of tanh (the CPU cell allows it, rnn.py:57-58,
+// 292-293; the reference's CUDA classes fix tanh).  Instantiated for fp32 time- or batch-major sequences without
+// PREIN; hs only or the one-saved-tensor contract.
+template <int GATE, int AUX, bool RAGGED, bool BF = false, bool F16H = true, bool PREIN = false, bool UQ = false>
 __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     int Tn, int B, int rsT, int rsB, int mode, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                                                        // .cu:55-58
       const float z = gate_act<GATE>(a[r] + bzv[r]);
-      const float c = ftanh(a[r] + bhv[r]);
+      const float c = UQ ? fminf(fmaxf(a[r] + bhv[r], -1.0f), 1.0f) : ftanh(a[r] + bhv[r]);
       hown[r] = (sz * (1.0f - z) + sn) * c + hown[r] * z;
       zq[r] = z; cq[r] = c;
     }
@@ -691,7 +694,8 @@ struct BwdW8Lds {
 // involves W or x leaves the scan: it writes d_pre[T,B,H] (fp32, through the d_x pointer) and the batched GEMMs of
 // kernels_gemm.hip produce  dW = d_pre^T X  and  d_x = d_pre W  afterwards (.cu:538-539 does both per step).  The
 // recurrence, dU (eight column tiles, four per column half) and the bias / zeta / nu sums stay as they are.
-template <int GATE, bool PREACT, bool RAGGED, bool BF = false, bool NOX = false>
+// UQ: update nonlinearity quantTanh (see fwd_scan_split_w8); PREACT contract only.
+template <int GATE, bool PREACT, bool RAGGED, bool BF = false, bool NOX = false, bool UQ = false>
 __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     int Tn, int B, int rsT, int rsB, int mode, const float* __restrict__ ghs, const float* __restrict__ x,
     const float* __restrict__ hs, const float* __restrict__ aux0, const float* __restrict__ aux1,
@@ -842,11 +846,12 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       float z, c;
       if (PREACT) {
         z = gate_act<GATE>(e.a0[r] + bzq[r]);
-        c = ftanh(e.a0[r] + bhq[r]);
+        c = UQ ? fminf(fmaxf(e.a0[r] + bhq[r], -1.0f), 1.0f) : ftanh(e.a0[r] + bhq[r]);
       } else {
         z = e.a0[r]; c = e.a1[r];
       }
-      f.kc[r] = (sz * (1.0f - z) + sn) * (1.0f - c * c);        // d_pre_c = kc * gg   (.cu:109)
+      const float dc = UQ ? ((c < 1.0f && c > -1.0f) ? 1.0f : 0.0f) : 1.0f - c * c;      // update nonlinearity's derivative
+      f.kc[r] = (sz * (1.0f - z) + sn) * dc;                    // d_pre_c = kc * gg   (.cu:109)
       f.kz[r] = (e.h[r] - sz * c) * gate_dact<GATE>(z);         // d_pre_z = kz * gg   (.cu:110)
       f.z[r] = z; f.c[r] = c;
     }
@@ -1175,7 +1180,9 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, wide ? dpre : (float*)g.d_x, (float*)g.d_h0, part);
   };
-  if (wide) {                                        // fp32 sequences (split_supported); both saved-tensor contracts
+  if (d.update_nl == FASTGRNN_NL_QUANT_TANH) {       // fp32, SAVE_PREACT, F = 32 (split_supported)
+    if (ragged) go8(bwd_scan_split_w8<GATE, true, true, false, false, true>); else go8(bwd_scan_split_w8<GATE, true, false, false, false, true>);
+  } else if (wide) {                                 // fp32 sequences (split_supported); both saved-tensor contracts
     if (preact) { if (ragged) go8(bwd_scan_split_w8<GATE, true, true, false, true>); else go8(bwd_scan_split_w8<GATE, true, false, false, true>); }
     else        { if (ragged) go8(bwd_scan_split_w8<GATE, false, true, false, true>); else go8(bwd_scan_split_w8<GATE, false, false, false, true>); }
   } else if (d.dtype == FASTGRNN_BF16_IO) {
@@ -1716,6 +1723,15 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   const bool bf = d.dtype == FASTGRNN_BF16_IO;
   auto pick8 = [&](auto aux_tag) __attribute__((always_inline)) {
     constexpr int A = decltype(aux_tag)::value;
+    if constexpr (A == 0 || A == 2) {
+      if (d.update_nl == FASTGRNN_NL_QUANT_TANH) {   // fp32, no PREIN (split_supported)
+        if constexpr (BOUNDED) {
+          if (h16) { if (ragged) go8(fwd_scan_split_w8<GATE, A, true, false, true, false, true>); else go8(fwd_scan_split_w8<GATE, A, false, false, true, false, true>); return; }
+        }
+        if (ragged) go8(fwd_scan_split_w8<GATE, A, true, false, false, false, true>); else go8(fwd_scan_split_w8<GATE, A, false, false, false, false, true>);
+        return;
+      }
+    }
     if (prein) {                                     // fp32 sequences only (split_supported)
       if constexpr (BOUNDED) {
         if (h16) {
@@ -1790,9 +1806,17 @@ bool lowrank_fwd_shape(const fastgrnn_desc& d) {
 }  // namespace
 
 bool split_supported(const fastgrnn_desc& d, int direction) {
-  if ((d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO) || d.update_nl != FASTGRNN_NL_TANH ||
+  if ((d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO) ||
+      (d.update_nl != FASTGRNN_NL_TANH && d.update_nl != FASTGRNN_NL_QUANT_TANH) ||
       d.gate_nl < FASTGRNN_NL_SIGMOID || d.gate_nl > FASTGRNN_NL_QUANT_SIGM4)
     return false;
+  if (d.update_nl == FASTGRNN_NL_QUANT_TANH) {
+    // quantTanh update (rnn.py:57-58,292-293): dense H = 128 / F = 32, fp32, hs only or the one-saved-tensor contract
+    const bool shape = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32 && d.dtype == FASTGRNN_F32 &&
+                       (double)d.T * d.B * 128 * 4.0 < 4294967296.0;
+    if (!shape || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST | FASTGRNN_FLAG_FWD_4WAVE))) return false;
+    return direction == 0 || (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  }
   // the 8-wave scans address a step's rows with 32-bit byte offsets from a scalar base: whole sequence tensors
   // below 2^32 bytes (B = 4096, T = 99, H = 128 is 2e8; anything larger goes to the other paths)
   const bool fits32 = (double)d.T * d.B * (d.H > d.F ? d.H : d.F) * 4.0 < 4294967296.0;

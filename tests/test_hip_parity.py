@@ -715,6 +715,50 @@ def test_quantised_gates_on_the_matrix_pipe(gate):
     _check_grads(g, g_o, 5e-5, gate)
 
 
+@pytest.mark.parametrize("gate,B", [("sigmoid", 64), ("quantSigm", 37), ("sigmoid", 4096)])
+def test_quant_tanh_update_on_the_matrix_pipe(gate, B):
+    """The CPU cell's quantTanh UPDATE nonlinearity (rnn.py:57-58,292-293; golden g7 pins the oracle for it) on the
+    8-wave split-precision kernels: c = clip(pre + b_h, -1, 1), dc/da = 1 inside (-1,1), 0 outside.  Forward against
+    the fp64 oracle; backward against the oracle on the kernel's own z, c (the clamp's derivative jumps)."""
+    T, F, H = (12, 32, 128) if B < 4096 else (99, 32, 128)
+    SAVE_PREACT, QT = 4, GATE_CODE["quantTanh"]
+    code = GATE_CODE[gate]
+    rng = np.random.default_rng(B)
+    p = O.make_params(F, H, dtype=np.float32, seed=17, randomize_scalars=True)
+    p["w"] = (3.0 * p["w"]).astype(np.float32)                  # update pre-activations on both sides of the clamp
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    P = _param_tensors(p)
+    xt, ht, Gt = _t(x), _t(h0), _t(G)
+    for direction, flags in ((0, 0), (0, SAVE_PREACT), (1, SAVE_PREACT)):
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, update_nl=QT, direction=direction, flags=flags) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, gate_nl=code, update_nl=QT, direction=1) != 2   # reference contract
+    hs, pre = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                           code, P["w1"], P["w2"], P["u1"], P["u2"], update_non_linearity=QT,
+                                           flags=SAVE_PREACT)
+    hs_only = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
+                                           code, P["w1"], P["w2"], P["u1"], P["u2"], update_non_linearity=QT,
+                                           want_gates=False)[0]
+    assert torch.equal(hs, hs_only)
+    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
+                                         P["w1"], P["w2"], P["u1"], P["u2"], code, update_non_linearity=QT,
+                                         flags=SAVE_PREACT, bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate, update="quantTanh")
+    assert (np.abs(hs.cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    inside = (cs_o > -1) & (cs_o < 1)
+    assert 0.2 < inside.mean() < 0.98, inside.mean()
+    pre_k = pre.cpu().numpy()
+    a = pre_k + p["bias_gate"]
+    zk = (1.0 / (1.0 + np.exp(-a.astype(np.float64))) if gate == "sigmoid" else np.clip((a + 1) / 2, 0, 1)).astype(np.float32)
+    ck = np.clip(pre_k + p["bias_update"], -1, 1).astype(np.float32)
+    g_o = O.unroll_backward(G, x, hs.cpu().numpy(), zk, ck, p, h0, gate=gate, update="quantTanh")
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u"]
+    g = {n: o.cpu().numpy() for n, o in zip(names, outs[:8])}
+    _check_grads(g, g_o, 5e-5, gate + "/quantTanh")
+
+
 @pytest.mark.parametrize("B,hs_batch_major", [(37, False), (64, False), (48, True)])
 def test_trainer_bft_input_layout_in_place(B, hs_batch_major):
     """FLAG_X_BFT: x / d_x in the data loader's [B,F,T] (trainClassifier.py:204 permutes it into
