@@ -96,7 +96,7 @@ int fastgrnn_hip_forward_unroll(const fastgrnn_desc* d, const fastgrnn_params* p
     return FASTGRNN_ERR_UNSUPPORTED;
   if ((d->flags & FASTGRNN_FLAG_HS_LAST) && z_s) return FASTGRNN_ERR_UNSUPPORTED;   // nothing is saved for a backward
   // (path 2 only needs its workspace when no auxiliary output is requested: see split_forward_ws)
-  const size_t need = (pick_path(d, 0) == 2 && z_s && !h256_shape(*d)) ? 0 : fastgrnn_hip_forward_workspace_bytes(d);
+  const size_t need = (pick_path(d, 0) == 2 && z_s && split_forward_ws_optional(*d)) ? 0 : fastgrnn_hip_forward_workspace_bytes(d);
   if ((st = check_ws(workspace, workspace_bytes, need))) return st;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (pick_path(d, 0)) {

@@ -71,6 +71,7 @@ int mfma_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
 bool split_supported(const fastgrnn_desc& d, int direction);
 size_t split_forward_ws(const fastgrnn_desc& d);
 size_t split_backward_ws(const fastgrnn_desc& d);
+bool split_forward_ws_optional(const fastgrnn_desc& d);   // the forward workspace is only used when z_s is NULL
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
                   void* hs, void* zs, void* cs, void* ws, hipStream_t s);
 int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
@@ -98,6 +99,16 @@ int h256_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x
                  void* cs, void* ws, hipStream_t s);
 int h256_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                   const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
+
+// low-rank H = 256 / F = 32 scans, ranks <= 16 (kernels_lowrank.hip), dispatched like the H = 256 dense ones
+bool lowrank_shape(const fastgrnn_desc& d);
+bool lowrank_supported(const fastgrnn_desc& d, int direction);
+size_t lowrank_forward_ws(const fastgrnn_desc& d);
+size_t lowrank_backward_ws(const fastgrnn_desc& d);
+int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
+                    void* cs, void* ws, hipStream_t s);
+int lowrank_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                     const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
 
 // classifier head on the last state: Linear + log_softmax + NLL, forward and backward (kernels_head.hip)
 bool head_supported(int B, int H, int C);

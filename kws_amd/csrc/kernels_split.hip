@@ -457,188 +457,6 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// forward, low-rank  (H = 256, F = 32, wRank = uRank = 16: BASELINE config 4)
-// ------------------------------------------------------------------------------------------
-// pre = W2 (W1 x) + U2 (U1 h), evaluated factorised like the CPU cell (rnn.py:280-287).  Workgroup =
-// NW waves = 16 utterances; wave w owns hidden units UPW*w .. (NW = 8: 32 units, two 16-row tiles; NW = 4: 64
-// units, four tiles) and a lane its UPW/4 consecutive units.  All factor planes are resident in registers.
-//   A  m_h partial: U1 contracted over the wave's OWN 64 units -- the B operand is the lane's own
-//      two fragments of h, straight from registers (h never goes through LDS); m_x = W1 x.
-//   -  the four partials (and m_x, from wave 0) meet in a 16 KB LDS buffer: ONE barrier per step
-//   B  pre tile = [U2 | W2] . [m_h ; m_x]: K = 16 + 16 = one K-step of 32, four row tiles per wave,
-//      run one after the other so that each tile's epilogue sits under the next tile's MFMAs.
-template <int GATE, int AUX, bool RAGGED, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
-    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
-    const float* __restrict__ w1, const float* __restrict__ w2,
-    const float* __restrict__ u1, const float* __restrict__ u2,
-    const float* __restrict__ bz, const float* __restrict__ bh,
-    const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs) {
-  // NW waves per workgroup (8 = two per SIMD: one wave's VALU epilogue runs beside the other's MFMAs / LDS round
-  // trip; 4 = the first shape, kept for A/B).  UPW units per wave, NT row tiles, KU K-steps of U1 over own units.
-  constexpr int H = 256, F = 32, R = 16, UPW = H / NW, NT = UPW / 16, KU = UPW / 32, UPL = UPW / 4;
-  constexpr int MROW = 36;   // padded floats per (wave, utterance) row of m
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
-  __shared__ __attribute__((aligned(16))) float msum[2][16][MROW];   // NW == 8: the summed rank-space vector
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63, i = l & 15, g = l >> 4;
-  const int b = blockIdx.x * 16 + i;
-  const bool valid = !RAGGED || b < B;
-  const int bc = valid ? b : B - 1;
-  const int n0 = wv * UPW + g * UPL;               // this lane's UPL consecutive hidden units
-
-  // ---- resident A operands -----------------------------------------------------------------
-  Frag3 U1f[KU], W1f, UW2f[NT];
-#pragma unroll
-  for (int v = 0; v < KU; ++v) {                   // rows = rank index i; K-step v = units n0 + 8v + j of lane group g
-    const float* p = u1 + (size_t)i * H + n0 + 8 * v;
-    U1f[v] = split3(ld4(p), ld4(p + 4));
-  }
-  {
-    const float* p = w1 + (size_t)i * F + 8 * g;
-    W1f = split3(ld4(p), ld4(p + 4));
-  }
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {                // rows = units; K = [m_h rows 8g.. | m_x rows 8(g-2)..]
-    const int nA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
-    const float* p = (g < 2) ? u2 + (size_t)nA * R + 8 * g : w2 + (size_t)nA * R + 8 * (g - 2);
-    UW2f[mt] = split3(ld4(p), ld4(p + 4));
-  }
-  f32x4 bzv[NT], bhv[NT], hown[NT];
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-    bzv[mt] = ld4(bz + n0 + 4 * mt);
-    bhv[mt] = ld4(bh + n0 + 4 * mt);
-    hown[mt] = ld4(h0 + (size_t)bc * H + n0 + 4 * mt);
-  }
-  Frag3 hfrag[KU];
-#pragma unroll
-  for (int v = 0; v < KU; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
-  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
-
-  struct Feat { f32x4 lo, hi; };
-  struct Gates { f32x4 z[NT], c[NT], mlo, mhi; };
-  auto load_x = [&](int t, Feat& q) __attribute__((always_inline)) {
-    const float* xp = x + ((size_t)t * B + bc) * F + 8 * g;
-    q.lo = ld4(xp); q.hi = ld4(xp + 4);
-  };
-  auto store_step = [&](int t, const Gates& gt) __attribute__((always_inline)) {   // hown still holds h_t
-    if (valid) {
-      const size_t o = ((size_t)t * B + b) * H + n0;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) st4(hs + o + 4 * mt, hown[mt]);
-      if (AUX == 1) {
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
-      } else if (AUX == 2) {
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);      // gt.z carries the pre-activation
-        // [m_h | m_x] of the step: cs is [T,B,32] in this mode; every wave holds the same sum, wave w
-        // stores lane groups g == w (8 floats each)
-        if (g == wv) {
-          float* mo = cs + ((size_t)t * B + b) * 32 + 8 * g;
-          st4(mo, gt.mlo); st4(mo + 4, gt.mhi);
-        }
-      }
-    }
-  };
-
-  auto step = [&](auto first_tag, int t, int cur, Feat& xuse, Feat& xload, Gates& gprev,
-                  Gates& gout) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    // ---- A: rank-space partials ------------------------------------------------------------
-    const Frag3 xB = split3(xuse.lo, xuse.hi);
-    // xB is needed inside a wave-uniform branch only; left alone the compiler sinks the split AND the load of
-    // x_0 into that branch, i.e. behind the MFMAs below and into their dead operand registers (the first step
-    // of the 4-wave variant came out wrong that way).  The empty asm pins the planes here (operand rule, 4.0).
-    asm volatile("" :: "v"(xB.p[0]), "v"(xB.p[1]), "v"(xB.p[2]));
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 mh = mfma6(U1f[0], hfrag[0], f32x4{0.f, 0.f, 0.f, 0.f});                      // rnn.py:286 (partial over own units)
-    if constexpr (KU == 2) mh = mfma6(U1f[1], hfrag[1], mh);
-    f32x4 mx = f32x4{0.f, 0.f, 0.f, 0.f};                                               // m_x enters the sum once:
-    if (wv == 0) mx = mfma6(W1f, xB, mx);                                               // wave 0 (uniform branch); rnn.py:280
-    if (!FIRST) store_step(t - 1, gprev);
-    // lane (b=i, g) holds rows 4g..4g+3 of both 16-row results
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh;
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx;
-    lds_barrier();
-    // The request for x_{t+1} goes out here: every MFMA issued so far has retired (its result went through LDS
-    // above), so the load cannot land in an operand register that the matrix pipe still has to fetch.
-    load_x(t + 1 < Tn ? t + 1 : t, xload);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- m = sum of the partials; this lane's B fragment is rows 8g..8g+7 of [m_h ; m_x] -------
-    f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
-    if constexpr (NW == 8) {
-      // Two stages: every wave needs the whole sum, and eight waves each reading all eight partials is 131 KB of
-      // LDS reads per step.  512 threads = 16 utterances x 32 values: each adds ONE value's eight partials (same
-      // order as below: identical bits), the sums go through a 2 KB buffer and one more barrier.
-      const int u = tid & 15, j = tid >> 4;
-      float sj = 0.f;
-#pragma unroll
-      for (int w2i = 0; w2i < NW; ++w2i) sj += mp[cur][w2i][u][j];
-      msum[cur][u][j] = sj;
-      lds_barrier();
-      mlo = *reinterpret_cast<const f32x4*>(&msum[cur][i][8 * g]);
-      mhi = *reinterpret_cast<const f32x4*>(&msum[cur][i][8 * g + 4]);
-    } else {
-#pragma unroll
-      for (int w2i = 0; w2i < NW; ++w2i) {
-        mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
-        mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
-      }
-    }
-    if (AUX == 2) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
-    const Frag3 mB = split3(mlo, mhi);
-    // ---- B: pre-activation tiles, epilogue of tile k under the MFMAs of tile k+1 -----------------
-    f32x4 acc[NT];
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      acc[mt] = mfma6(UW2f[mt], mB, f32x4{0.f, 0.f, 0.f, 0.f});                          // rnn.py:281,287,289
-      if (mt > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                                                    // .cu:55-58, tile mt-1
-          const float pre = acc[mt - 1][r];
-          const float z = gate_act<GATE>(pre + bzv[mt - 1][r]);
-          const float c = ftanh(pre + bhv[mt - 1][r]);
-          hown[mt - 1][r] = (sz * (1.0f - z) + sn) * c + hown[mt - 1][r] * z;
-          gout.z[mt - 1][r] = (AUX == 2) ? pre : z; gout.c[mt - 1][r] = c;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float pre = acc[NT - 1][r];
-      const float z = gate_act<GATE>(pre + bzv[NT - 1][r]);
-      const float c = ftanh(pre + bhv[NT - 1][r]);
-      hown[NT - 1][r] = (sz * (1.0f - z) + sn) * c + hown[NT - 1][r] * z;
-      gout.z[NT - 1][r] = (AUX == 2) ? pre : z; gout.c[NT - 1][r] = c;
-    }
-#pragma unroll
-    for (int v = 0; v < KU; ++v) hfrag[v] = split3(hown[2 * v], hown[2 * v + 1]);
-  };
-
-  Feat xa, xb;
-  Gates ga, gb;
-  load_x(0, xa);
-  __builtin_amdgcn_sched_barrier(0);         // every prologue request is out before the first MFMA
-  step(std::true_type{}, 0, 0, xa, xb, gb, ga);
-  int t = 1;
-  for (; t + 1 < Tn; t += 2) {
-    step(std::false_type{}, t, 1, xb, xa, ga, gb);
-    step(std::false_type{}, t + 1, 0, xa, xb, gb, ga);
-  }
-  if (t < Tn) {
-    step(std::false_type{}, t, 1, xb, xa, ga, gb);
-    store_step(Tn - 1, gb);
-  } else {
-    store_step(Tn - 1, ga);
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // backward  (H = 128, F = 32)
@@ -1206,492 +1024,6 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward, low-rank  (H = 256, F = 32, wRank = uRank = 16), FASTGRNN_FLAG_SAVE_PREACT contract only
-// ------------------------------------------------------------------------------------------
-// Mirror of fwd_scan_lowrank_split.  Per step: EW on the VALU (z, c recomputed from the saved
-// pre-activation) -> d_pre; rank-space partial [U2|W2]^T d_pre over the wave's OWN units with the B
-// operand straight from registers; the four partials meet in LDS (one barrier); d_h = z*g + U1^T d_m_h
-// for the wave's own units and d_x = W1^T d_m_x.  d_pre[T,B,H] and d_m[T,B,32] go to the workspace:
-// the weight gradients (K = T*B) are contracted afterwards by split-K GEMMs (.cu:546-555 evaluated
-// factorised), because neither their accumulators nor the images they would need fit on chip beside
-// the factors.
-constexpr int SLAB_LR = 576;   // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded to 64
-
-template <int GATE, bool RAGGED, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
-    int Tn, int B, const float* __restrict__ ghs, const float* __restrict__ hs, const float* __restrict__ pre_s,
-    const float* __restrict__ h0, const float* __restrict__ w1, const float* __restrict__ w2,
-    const float* __restrict__ u1, const float* __restrict__ u2,
-    const float* __restrict__ bz, const float* __restrict__ bh,
-    const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ d_x, float* __restrict__ d_h0,
-    float* __restrict__ dpre_ws, float* __restrict__ dm_ws, float* __restrict__ part) {
-  // NW waves (8 = two per SIMD, 32 units each; 4 = the first shape): see fwd_scan_lowrank_split
-  constexpr int H = 256, F = 32, R = 16, UPW = H / NW, NT = UPW / 16, KU = UPW / 32, UPL = UPW / 4, MROW = 36;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
-  __shared__ __attribute__((aligned(16))) float sbias[2][H];
-  __shared__ float red[2 * NW];
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63, i = l & 15, g = l >> 4;
-  const int b = blockIdx.x * 16 + i;
-  const bool valid = !RAGGED || b < B;
-  const int bc = valid ? b : B - 1;
-  const int n0 = wv * UPW + g * UPL;
-  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
-  if (tid < H) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
-
-  // ---- resident A operands -----------------------------------------------------------------
-  // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units: tile 0 rows = U2 columns, tile 1 = W2 columns
-  Frag3 UW2Tf[2][KU];
-#pragma unroll
-  for (int tl = 0; tl < 2; ++tl) {
-    const float* src = tl == 0 ? u2 : w2;
-#pragma unroll
-    for (int v = 0; v < KU; ++v) {
-      f32x4 lo, hi;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = src[(size_t)(n0 + 8 * v + j) * R + i];
-        hi[j] = src[(size_t)(n0 + 8 * v + 4 + j) * R + i];
-      }
-      UW2Tf[tl][v] = split3(lo, hi);
-    }
-  }
-  // d_h[k][b] = z*g + sum_j U1[j][k] d_m_h[j][b]: rows = own units, K = [d_m_h rows 8g.. | nothing]
-  Frag3 U1Tf[NT];
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) {
-    const int kA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
-    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-    if (g < 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = u1[(size_t)(8 * g + j) * H + kA];
-        hi[j] = u1[(size_t)(8 * g + 4 + j) * H + kA];
-      }
-    }
-    U1Tf[mt] = split3(lo, hi);
-  }
-  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv&1 (stored by waves 0,1), K = [nothing | d_m_x rows 8(g-2)..]
-  Frag3 W1Tf;
-  {
-    const int f = (wv & 1) * 16 + i;
-    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-    if (g >= 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = w1[(size_t)(8 * (g - 2) + j) * F + f];
-        hi[j] = w1[(size_t)(8 * (g - 2) + 4 + j) * F + f];
-      }
-    }
-    W1Tf = split3(lo, hi);
-  }
-
-  f32x4 sbz[NT], sbh[NT], dh[NT];
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
-  float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;     // d_zeta / d_nu partial sums, compensated
-
-  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
-  // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
-  // of a 64-bit pointer pair each (the host rejects B*H*4 >= 2^31 for this path).
-  const unsigned lane_h = (unsigned)bc * H + n0, lane_hs = (unsigned)b * H + n0;
-  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t step = (size_t)t * B * H;                                   // uniform
-    const float* gt = ghs + step;
-    const float* pt = pre_s + step;
-    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)B * H);          // .cu:478-481
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero, so gg,
-      // d_pre and every sum they enter stay exactly zero for them; see bwd_scan_split_w8)
-      e.g[mt] = (RAGGED && !valid) ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(gt + lane_h + 4 * mt);
-      e.a0[mt] = ld4(pt + lane_h + 4 * mt);
-      e.h[mt] = ld4(ht + lane_h + 4 * mt);
-    }
-  };
-
-  auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const int cur = t & 1;
-    {
-      // dh read = the previous step's MFMAs have retired: the requests below may land in registers they read
-      // (operand rule)
-      float touch = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
-      if (touch == 1.2345678e38f) red[0] = 1.f;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
-    f32x4 dpv[NT];
-    float sz8 = 0.f, sn8 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 4 * mt]);
-      const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 4 * mt]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z = gate_act<GATE>(e.a0[mt][r] + bzq[r]);
-        const float c = ftanh(e.a0[mt][r] + bhq[r]);
-        const float gg = e.g[mt][r] + dh[mt][r];                                 // .cu:474
-        const float dcp = (sz * (1.0f - z) + sn) * (1.0f - c * c) * gg;          // .cu:109
-        const float dzp = (e.h[mt][r] - sz * c) * gate_dact<GATE>(z) * gg;       // .cu:110
-        const float zg = z * gg;                                                  // .cu:108
-        const float tz = (1.0f - z) * c * gg, tn = c * gg;                        // .cu:114-115
-        sbz[mt][r] += dzp; sbh[mt][r] += dcp; sz8 += tz; sn8 += tn;
-        dpv[mt][r] = dzp + dcp;                                                   // .cu:113
-        dh[mt][r] = zg;
-      }
-    }
-    kahan_add(pz, pz_c, sz8); kahan_add(pn, pn_c, sn8);
-    // EW(t) has consumed the operand set (and read dh: the previous step's MFMAs have retired): refill it for t-1
-    __builtin_amdgcn_sched_barrier(0);
-    if (t > 0) load_ew(t - 1, e);
-    __builtin_amdgcn_sched_barrier(0);
-    if (valid) {
-      float* o = dpre_ws + (size_t)t * B * H + lane_hs;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) st4(o + 4 * mt, dpv[mt]);
-    }
-    // ---- rank-space partial over own units: B operand = this lane's two fragments of d_pre ----
-    Frag3 dfr[KU];
-#pragma unroll
-    for (int v = 0; v < KU; ++v) dfr[v] = split3(dpv[2 * v], dpv[2 * v + 1]);
-    // big and small terms in accumulators of their own, as in the dense scans (mfma6_hl: inside one MFMA the
-    // addends are chopped at the largest one, a one-signed loss that showed in d_zeta / d_nu at B = 4096)
-    f32x4 mh = f32x4{0.f, 0.f, 0.f, 0.f}, mx = mh, mhl = mh, mxl = mh;
-#pragma unroll
-    for (int v = 0; v < KU; ++v) mfma6_hl(UW2Tf[0][v], dfr[v], mh, mhl);
-#pragma unroll
-    for (int v = 0; v < KU; ++v) mfma6_hl(UW2Tf[1][v], dfr[v], mx, mxl);
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh + mhl;
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx + mxl;
-    lds_barrier();
-    f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
-    // (the forward's two-stage sum was tried here too: 1 % at most, and its extra registers made the kernel spill)
-#pragma unroll
-    for (int w2i = 0; w2i < NW; ++w2i) {
-      mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
-      mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
-    }
-    if (wv == 0 && valid) {                          // [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
-      float* mo = dm_ws + (size_t)t * B * 32 + ((unsigned)b * 32 + 8 * g);
-      st4(mo, mlo); st4(mo + 4, mhi);
-    }
-    const Frag3 mB = split3(mlo, mhi);
-    // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
-    f32x4 dlo[NT];
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) { dlo[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; mfma6_hl(U1Tf[mt], mB, dh[mt], dlo[mt]); }
-    if (wv < 2) {                                    // (wave-uniform) feature tile wv
-      f32x4 dxv = f32x4{0.f, 0.f, 0.f, 0.f}, dxl = dxv;
-      mfma6_hl(W1Tf, mB, dxv, dxl);
-      dxv += dxl;
-      if (valid) st4(d_x + (size_t)t * B * F + ((unsigned)b * F + wv * 16 + 4 * g), dxv);
-      // these are the step's youngest MFMAs: an unconditional read of their result (the store above is skipped
-      // by lanes beyond a ragged batch) before the next step's requests may reuse their operand registers
-      if (RAGGED && dxv[0] == 1.2345678e38f) red[1] = 1.f;
-    }
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
-  };
-
-  EwOps ea;                                          // ONE operand set, refilled right behind its use (see step)
-  __syncthreads();                                   // sbias
-  load_ew(Tn - 1, ea);
-  for (int t = Tn - 1; t >= 0; --t) step(t, ea);
-  {
-    // the last step's MFMAs have retired before anything below (stores masked by `valid`, the reductions' LDS
-    // traffic) may reuse their operand registers: an unconditional read of every d_h accumulator
-    float touch = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
-    if (touch == 1.2345678e38f) red[0] = 1.f;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // ---- flush ---------------------------------------------------------------------------------
-  if (valid) {
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
-  }
-#pragma unroll
-  for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a = sbz[mt][r], c = sbh[mt][r];
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
-      if (i == 0) {
-        float* pb = part + (size_t)blockIdx.x * SLAB_LR;
-        pb[n0 + 4 * mt + r] = a;
-        pb[H + n0 + 4 * mt + r] = c;
-      }
-    }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
-  if (l == 0) { red[wv] = pz; red[NW + wv] = pn; }
-  __syncthreads();
-  if (tid == 0) {
-    float* pzn = part + (size_t)blockIdx.x * SLAB_LR + 2 * H;
-    float a = 0.f, c = 0.f;
-#pragma unroll
-    for (int w2i = 0; w2i < NW; ++w2i) { a += red[w2i]; c += red[NW + w2i]; }
-    pzn[0] = a; pzn[1] = c;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// C[M,N] = A[:, :M]^T . B[:, :N] over R rows (R = T*B, huge; M, N small): split-precision, matrix pipe
-// ------------------------------------------------------------------------------------------
-// The weight gradients of the low-rank backward (.cu:546-555, factorised).  Workgroup = 4 waves = one
-// chunk of TN_CHUNK rows, staged 32 rows at a time: global fp32 -> three exact bf16 planes in LDS in
-// natural [row][column] order -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs into
-// register accumulators.  Each workgroup leaves its partial C in the workspace; tn_reduce sums them
-// in a fixed order.  MT x NT = 16x16 tiles of C; wave w owns tiles w, w+4, ...
-constexpr int TN_CHUNK = 800, TN_STAGE = 32;
-
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __restrict__ A, int lda,
-                                                     const float* __restrict__ B0, const float* __restrict__ B1,
-                                                     size_t shiftB, int ldb, float* __restrict__ part) {
-  constexpr int M = MT * 16, N = NT * 16, ROWA = M * 2 + 32, ROWB = N * 2 + 32;
-  constexpr int NTILE = MT * NT, TPW = (NTILE + 3) / 4;
-  constexpr int VA = (TN_STAGE * M / 4 + 255) / 256, VB = (TN_STAGE * N / 4 + 255) / 256;   // float4 per thread per stage
-  __shared__ __attribute__((aligned(16))) unsigned char la[3][TN_STAGE * ROWA];
-  __shared__ __attribute__((aligned(16))) unsigned char lb[3][TN_STAGE * ROWB];
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
-  const size_t r_begin = (size_t)blockIdx.x * TN_CHUNK;
-  const size_t r_end = (r_begin + TN_CHUNK < R) ? r_begin + TN_CHUNK : R;
-
-  f32x4 va[VA], vb[VB];
-  auto load_stage = [&](size_t r0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < VA; ++j) {
-      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
-      const size_t r = r0 + row;
-      va[j] = (idx < TN_STAGE * M / 4 && r < r_end) ? ld4(A + r * lda + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int j = 0; j < VB; ++j) {
-      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
-      const size_t r = r0 + row;
-      const float* src = r < shiftB ? B0 + r * ldb : B1 + (r - shiftB) * ldb;   // H_prev: rows of t = 0 are h0
-      vb[j] = (idx < TN_STAGE * N / 4 && r < r_end) ? ld4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto split4 = [&](const f32x4 v, unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned off)
-      __attribute__((always_inline)) {
-    uint2 q0, q1, q2;
-    split_quad(v, q0, q1, q2);
-    *reinterpret_cast<uint2*>(p0 + off) = q0;
-    *reinterpret_cast<uint2*>(p1 + off) = q1;
-    *reinterpret_cast<uint2*>(p2 + off) = q2;
-  };
-  auto publish = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < VA; ++j) {
-      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
-      if (idx < TN_STAGE * M / 4) split4(va[j], la[0], la[1], la[2], (unsigned)(row * ROWA + c4 * 8));
-    }
-#pragma unroll
-    for (int j = 0; j < VB; ++j) {
-      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
-      if (idx < TN_STAGE * N / 4) split4(vb[j], lb[0], lb[1], lb[2], (unsigned)(row * ROWB + c4 * 8));
-    }
-  };
-
-  f32x4 acc[TPW];
-#pragma unroll
-  for (int k = 0; k < TPW; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const unsigned la0 = (unsigned)(size_t)&la[0][0], lb0 = (unsigned)(size_t)&lb[0][0];
-  // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
-  const unsigned trA = la0 + (8 * g + q) * ROWA + 4 * pp * 2;
-  const unsigned trB = lb0 + (8 * g + q) * ROWB + 4 * pp * 2;
-
-  load_stage(r_begin);
-  for (size_t r0 = r_begin; r0 < r_end; r0 += TN_STAGE) {
-    __syncthreads();                                 // the previous stage's fragment reads are done
-    publish();
-    __syncthreads();
-    if (r0 + TN_STAGE < r_end) load_stage(r0 + TN_STAGE);
-    // Several waves share a SIMD here (2 workgroups per CU): all of a batch's fragment reads are issued,
-    // into registers of their own, before its first MFMA, and the MFMAs have retired before the next batch or
-    // stage reloads them (operand rule).  A wave's tiles wv, wv+4, ... share their B fragment
-    // when NT divides 4 (nt = wv % NT) and their A fragment when MT == 1: those are read once.  Batches of at
-    // most four tiles keep the kernel under 128 registers' worth of fragments (two workgroups per CU).
-    constexpr bool A_CONST = (MT == 1), B_CONST = (4 % NT == 0);
-    constexpr int BATCH = TPW < 4 ? TPW : 4;
-    Frag3 fa1, fb1;
-    if (A_CONST) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa1.p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA), ROWA);
-    }
-    if (B_CONST) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb1.p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + (wv % NT) * 32, ROWB);
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < TPW; k0 += BATCH) {
-      Frag3 fa[BATCH], fb[BATCH];
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) {            // wave-uniform
-          const int mt = tile / NT, nt = tile % NT;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            if (!A_CONST) fa[k].p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA) + mt * 32, ROWA);
-            if (!B_CONST) fb[k].p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + nt * 32, ROWB);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float touch = 0.f;
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) {
-          acc[k0 + k] = mfma6(A_CONST ? fa1 : fa[k], B_CONST ? fb1 : fb[k], acc[k0 + k]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks MFMAs below the read)
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) touch += acc[k0 + k][0];
-      }
-      if (touch == 1.2345678e38f) part[0] = 1.f;       // VALU read of every accumulator: the MFMAs have retired
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // D row 4g + r of tile (mt, nt) is m = 16mt + 4g + r, column n = 16nt + (l & 15)
-  float* pc = part + (size_t)blockIdx.x * M * N;
-#pragma unroll
-  for (int k = 0; k < TPW; ++k) {
-    const int tile = wv + 4 * k;
-    if (tile < NTILE) {
-      const int mt = tile / NT, nt = tile % NT;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pc[(size_t)(mt * 16 + 4 * g + r) * N + nt * 16 + (l & 15)] = acc[k][r];
-    }
-  }
-}
-
-// C[idx] = sum over workgroups, fixed order; optional column split of a [M, 32] result into two [M, 16]
-__global__ __launch_bounds__(1024) void tn_reduce(int nwg, int MN, const float* __restrict__ part,
-                                                  float* __restrict__ C0, float* __restrict__ C1, int split16) {
-  __shared__ float sm[16][64];
-  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  float a = 0.f;
-  if (idx < MN) {
-    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * MN + idx] : 0.f; }
-      a += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-  }
-  sm[pid][o] = a;
-  __syncthreads();
-  if (pid == 0 && idx < MN) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += sm[j][o];
-    if (split16) { const int n = idx >> 5, j = idx & 31; if (j < 16) C0[n * 16 + j] = t; else C1[n * 16 + (j - 16)] = t; }
-    else C0[idx] = t;
-  }
-}
-
-static inline int tn_nwg(size_t R) { return (int)((R + TN_CHUNK - 1) / TN_CHUNK); }
-
-// bias / zeta / nu gradients of the low-rank backward: fixed-order sum over workgroups
-__global__ __launch_bounds__(1024) void reduce_lowrank_small(int nwg, const float* __restrict__ part,
-                                                             const float* __restrict__ zeta, const float* __restrict__ nu,
-                                                             float* __restrict__ d_bz, float* __restrict__ d_bh,
-                                                             float* __restrict__ d_zeta, float* __restrict__ d_nu) {
-  __shared__ float sm[16][64];
-  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;               // 0 .. 2*256+1
-  float a = 0.f;
-  if (idx < 2 * 256 + 2) {
-    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * SLAB_LR + idx] : 0.f; }
-      a += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-  }
-  sm[pid][o] = a;
-  __syncthreads();
-  if (pid == 0 && idx < 2 * 256 + 2) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += sm[j][o];
-    if (idx < 256) d_bz[idx] = t;
-    else if (idx < 512) d_bh[idx - 256] = t;
-    else if (idx == 512) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
-    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                      // .cu:117,545
-  }
-}
-
-struct LowrankBwdWs { size_t dpre, dm, part, splitk, total; };
-LowrankBwdWs lowrank_bwd_layout(const fastgrnn_desc& d) {
-  const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
-  LowrankBwdWs L; size_t o = 0;
-  L.dpre = o; o += align256(TB * 256 * 4);
-  L.dm = o; o += align256(TB * 32 * 4);
-  L.part = o; o += align256(nwg * SLAB_LR * 4);
-  L.splitk = o; o += align256((size_t)tn_nwg(TB) * 256 * 32 * 4);   // partial C of the largest product, per workgroup
-  L.total = o;
-  return L;
-}
-
-template <int GATE>
-void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,
-                             const void* hs, const void* pre_s, const void* m_s, const void* h0,
-                             const fastgrnn_grads& g, void* ws, hipStream_t s) {
-  const LowrankBwdWs L = lowrank_bwd_layout(d);
-  char* base = reinterpret_cast<char*>(ws);
-  float* dpre = (float*)(base + L.dpre); float* dm = (float*)(base + L.dm); float* part = (float*)(base + L.part);
-  float* splitk = (float*)(base + L.splitk);
-  const int nwg = (d.B + 15) / 16;
-  const size_t TB = (size_t)d.T * d.B;
-  auto go = [&](auto kern, int threads) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), 0, s, d.T, d.B, (const float*)ghs, (const float*)hs,
-                       (const float*)pre_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
-                       (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate, (const float*)p.bias_update,
-                       (const float*)p.zeta, (const float*)p.nu, (float*)g.d_x, (float*)g.d_h0, dpre, dm, part);
-  };
-  // 8 waves (two per SIMD) for full and ragged batches alike (lanes beyond a ragged batch only get a zero gradient,
-  // which needs no extra registers; the first ragged variant masked five values per element and spilled)
-  if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, 8>, 512); else go(bwd_scan_lowrank_split<GATE, false, 8>, 512);
-  hipLaunchKernelGGL(reduce_lowrank_small, dim3((2 * 256 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
-                     (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
-                     (float*)g.d_nu);
-  // d_u2 | d_w2 = d_pre^T . [m_h | m_x]     (.cu:546-555, factorised)
-  const int ng = tn_nwg(TB);
-  hipLaunchKernelGGL((tn_gemm_split<16, 2>), dim3(ng), dim3(256), 0, s, TB, dpre, 256, (const float*)m_s,
-                     (const float*)m_s, (size_t)0, 32, splitk);
-  hipLaunchKernelGGL(tn_reduce, dim3(256 * 32 / 64), dim3(1024), 0, s, ng, 256 * 32, splitk, (float*)g.d_u2,
-                     (float*)g.d_w2, 1);
-  // d_u1 = d_m_h^T . H_prev  (rows of t = 0 are h0, the rest hs[t-1]);  d_w1 = d_m_x^T . X
-  hipLaunchKernelGGL((tn_gemm_split<1, 16>), dim3(ng), dim3(256), 0, s, TB, dm, 32, (const float*)h0,
-                     (const float*)hs, (size_t)d.B, 256, splitk);
-  hipLaunchKernelGGL(tn_reduce, dim3(16 * 256 / 64), dim3(1024), 0, s, ng, 16 * 256, splitk, (float*)g.d_u1,
-                     (float*)nullptr, 0);
-  hipLaunchKernelGGL((tn_gemm_split<1, 2>), dim3(ng), dim3(256), 0, s, TB, dm + 16, 32, (const float*)x,
-                     (const float*)x, (size_t)0, 32, splitk);
-  hipLaunchKernelGGL(tn_reduce, dim3(16 * 32 / 64), dim3(1024), 0, s, ng, 16 * 32, splitk, (float*)g.d_w1,
-                     (float*)nullptr, 0);
-}
 
 // pws != nullptr: PREIN -- the frame product P = X.W^T has been written by rows_gemm to zs (SAVE_PREACT), cs (the
 // reference's outputs) or, when the caller wants no auxiliary tensor, to the workspace pws
@@ -1774,34 +1106,6 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   }
 }
 
-template <int GATE>
-void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs,
-                             void* zs, void* cs, hipStream_t s) {
-  dim3 grid((d.B + 15) / 16), block(512);
-  const bool ragged = (d.B % 16) != 0;
-  auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w1,
-                       (const float*)p.w2, (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate,
-                       (const float*)p.bias_update, (const float*)p.zeta, (const float*)p.nu, (float*)hs, (float*)zs,
-                       (float*)cs);
-  };
-  const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
-  if (d.flags & FASTGRNN_FLAG_FWD_4WAVE) {             // A/B: the first shape, four waves of 64 units
-    block = dim3(256);
-    if (aux == 1)      { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true, 4>); else go(fwd_scan_lowrank_split<GATE, 1, false, 4>); }
-    else if (aux == 2) { if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true, 4>); else go(fwd_scan_lowrank_split<GATE, 2, false, 4>); }
-    else               { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, 4>); else go(fwd_scan_lowrank_split<GATE, 0, false, 4>); }
-    return;
-  }
-  if (aux == 1)      { if (ragged) go(fwd_scan_lowrank_split<GATE, 1, true>); else go(fwd_scan_lowrank_split<GATE, 1, false>); }
-  else if (aux == 2) { if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true>); else go(fwd_scan_lowrank_split<GATE, 2, false>); }
-  else               { if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true>); else go(fwd_scan_lowrank_split<GATE, 0, false>); }
-}
-
-bool lowrank_fwd_shape(const fastgrnn_desc& d) {
-  // B < 2^21: the scans address a step's rows with 32-bit lane offsets (B*H*4 bytes < 2^31)
-  return d.H == 256 && d.F == 32 && d.w_rank == 16 && d.u_rank == 16 && d.B < (1 << 21);
-}
 
 }  // namespace
 
@@ -1823,6 +1127,7 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   const bool dense = d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && d.F == 32 && fits32;
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (h256_shape(d)) return h256_supported(d, direction);      // dense H = 256 / F = 32: kernels_h256.hip
+  if (lowrank_shape(d)) return lowrank_supported(d, direction); // H = 256 / F = 32, ranks <= 16: kernels_lowrank.hip
   // dense H = 128 with a wider input (F = 64 / 128 / 256; the reference's second layer): recurrence-only scans +
   // batched GEMMs.  fp32 sequences, time- or batch-major, every gate, full or last-state outputs / gradients.
   if (dense_wide_shape(d)) {
@@ -1840,9 +1145,6 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   }
   // bf16 sequences: dense shape only; the backward only under the SAVE_PREACT contract (8-wave kernel)
   if (d.dtype == FASTGRNN_BF16_IO) return dense && (direction == 0 || preact);
-  // low-rank: forward always; backward only under the SAVE_PREACT contract (the reference-style
-  // backward with z_s / h_prime_s stays on the generic scan)
-  if (lowrank_fwd_shape(d)) return !(d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (direction == 0 || preact);
   return dense;
 }
 
@@ -1852,13 +1154,16 @@ size_t split_forward_ws(const fastgrnn_desc& d) {
   // it answers for that case; forward-only callers (HS_LAST or no gates) are the ones that pay.
   if (dense_wide_shape(d)) return align256((size_t)d.T * d.B * 128 * 4);
   if (h256_shape(d)) return h256_forward_ws(d);
+  if (lowrank_shape(d)) return lowrank_forward_ws(d);
   return 0;
 }
+
+bool split_forward_ws_optional(const fastgrnn_desc& d) { return dense_wide_shape(d); }
 
 size_t split_backward_ws(const fastgrnn_desc& d) {
   if (h256_shape(d)) return h256_backward_ws(d);
   if (dense_wide_shape(d)) return wide_bwd_layout(d).total;
-  if (lowrank_fwd_shape(d)) return lowrank_bwd_layout(d).total;
+  if (lowrank_shape(d)) return lowrank_backward_ws(d);
   return align256((size_t)((d.B + 15) / 16) * SLAB * 4);
 }
 
@@ -1866,15 +1171,7 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
                    const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws,
                    hipStream_t s) {
   if (h256_shape(d)) return h256_backward(d, p, ghs, x, hs, zs, cs, h0, g, ws, s);
-  if (lowrank_fwd_shape(d)) {
-    if (!cs) return FASTGRNN_ERR_NULL_POINTER;       // the rank-space vector saved by the forward
-    switch (d.gate_nl) {
-      case FASTGRNN_NL_SIGMOID: launch_bwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
-      case FASTGRNN_NL_RELU: launch_bwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
-      default: launch_bwd_lowrank_gate<FASTGRNN_NL_TANH>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
-    }
-    return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
-  }
+  if (lowrank_shape(d)) return lowrank_backward(d, p, ghs, x, hs, zs, cs, h0, g, ws, s);
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
@@ -1891,6 +1188,7 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
   if (!(d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (zs == nullptr) != (cs == nullptr)) return FASTGRNN_ERR_NULL_POINTER;
   if (d.dtype == FASTGRNN_BF16_IO && zs && !(d.flags & FASTGRNN_FLAG_SAVE_PREACT)) return FASTGRNN_ERR_UNSUPPORTED;
   if (h256_shape(d)) return h256_forward(d, p, x, h0, hs, zs, cs, ws, s);
+  if (lowrank_shape(d)) return lowrank_forward(d, p, x, h0, hs, zs, cs, ws, s);
   void* pws = nullptr;
   if (dense_wide_shape(d)) {
     // P[T*B,H] = X . W^T, the one genuinely dense contraction of the layer (.cu:356 per step), into the buffer the
@@ -1900,15 +1198,6 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
     if (!pws) return FASTGRNN_ERR_WORKSPACE;
     const int st = rows_gemm((size_t)d.T * d.B, 128, d.F, false, x, (const float*)p.w, pws, false, false, s);
     if (st != FASTGRNN_OK) return st;
-  }
-  if (lowrank_fwd_shape(d)) {
-    if ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (!zs || !cs)) return FASTGRNN_ERR_NULL_POINTER;
-    switch (d.gate_nl) {
-      case FASTGRNN_NL_SIGMOID: launch_fwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s); break;
-      case FASTGRNN_NL_RELU: launch_fwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, x, h0, hs, zs, cs, s); break;
-      default: launch_fwd_lowrank_gate<FASTGRNN_NL_TANH>(d, p, x, h0, hs, zs, cs, s); break;
-    }
-    return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
   }
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_fwd_gate<FASTGRNN_NL_SIGMOID>(d, p, x, h0, hs, zs, cs, s, pws); break;

@@ -206,10 +206,13 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         zs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates or preact) else None
         cs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates and not preact) else None
         if preact and desc.w_rank and desc.u_rank:
-            # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step
-            cs = torch.empty((T, B, desc.w_rank + desc.u_rank), dtype=pdt, device=dev)
-        # (kernel path 2 needs its forward workspace only when no auxiliary output is requested)
-        nbytes = 0 if (plan[1] == 2 and zs is not None and plan[3] > 65536) else plan[3]
+            # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step, always
+            # time-major and zero-extended to 16 + 16 columns (an opaque tensor for the backward)
+            cs = torch.empty((T * B, 32), dtype=pdt, device=dev)
+        # (dense H=128 layers with a wide input keep the frame product in the workspace only when no auxiliary
+        # output is requested: include/fastgrnn_hip.h, forward workspace)
+        wide = desc.H == 128 and desc.F > 32 and not desc.w_rank and not desc.u_rank
+        nbytes = 0 if (plan[1] == 2 and zs is not None and wide) else plan[3]
         ws, wsp = _workspace(nbytes, dev)
         fn = lib.fastgrnn_hip_forward_unroll if unrolled else lib.fastgrnn_hip_forward
         with _Timed("forward", dev):
@@ -232,7 +235,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         rank_space = h_prime if (_present(w1) and _present(u1)) else None
         if rank_space is not None:
             _check_input(rank_space, "rank_space")
-            _expect(rank_space, (input.shape[0], input.shape[1], w1.shape[0] + u1.shape[0]), "rank_space")
+            _expect(rank_space, (z.numel() // z.shape[-1], 32), "rank_space")
         h_prime = z              # keeps the shape checks below uniform
     for t, n in ((grad_h, "grad_h"), (input, "input"), (hs_or_old_h, "hidden_states" if unrolled else "old_h"),
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):

@@ -94,7 +94,7 @@ def test_argument_validation_without_launch(lib):
 
 
 def test_last_state_flags_are_refused_where_no_kernel_implements_them(lib):
-    """FLAG_GRAD_LAST / FLAG_HS_LAST exist on the dense 8-wave kernels only: every other path --
+    """FLAG_GRAD_LAST / FLAG_HS_LAST exist on the split-precision kernels only: every other path --
     and HS_LAST together with tensors saved for a backward -- answers FASTGRNN_ERR_UNSUPPORTED (7) before any
     launch; path selection reports the same."""
     null, one = C.c_void_p(None), C.c_void_p(256)
@@ -108,10 +108,16 @@ def test_last_state_flags_are_refused_where_no_kernel_implements_them(lib):
         g = _lib.Grads(*([one] * 12))
         assert lib.fastgrnn_hip_backward_unroll(C.byref(d), C.byref(pf), one, one, one, one, one, one, C.byref(g),
                                                 null, 0, null) == UNSUP
-    # other shapes (low-rank, odd sizes) have no last-state kernels either
+    # other shapes (ranks above 16, half-factorised cells, odd sizes) have no last-state kernels either
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_GRAD_LAST)), 1) == 2
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_HS_LAST)), 0) == 2
-    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=256, w_rank=16, u_rank=16, flags=_lib.FLAG_GRAD_LAST | _lib.FLAG_SAVE_PREACT)), 1) != 2
+    lr = dict(H=256, w_rank=16, u_rank=16)
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_GRAD_LAST | _lib.FLAG_SAVE_PREACT, **lr)), 1) == 2
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_GRAD_LAST, **lr)), 1) != 2      # reference contract
+    assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_HS_LAST, **lr)), 0) == 2
+    for w_rank, u_rank in ((32, 32), (16, 0), (0, 16), (17, 16)):
+        d = _desc(H=256, w_rank=w_rank, u_rank=u_rank, flags=_lib.FLAG_GRAD_LAST | _lib.FLAG_SAVE_PREACT)
+        assert lib.fastgrnn_hip_kernel_path(C.byref(d), 1) != 2
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=64, flags=_lib.FLAG_HS_LAST)), 0) != 2
     # HS_LAST with a tensor to save
     d = _desc(B=4, T=3, flags=_lib.FLAG_HS_LAST)

@@ -1,0 +1,175 @@
+"""GPU tests: the low-rank scans (H=256, F=32, ranks <= 16; kernels_lowrank.hip) offer what the dense H=128 scans do
+-- batch-major sequences, the data loader's [B,F,T] input, last-state-only gradients / outputs, bf16 sequences with
+fp32 master gradients (SURVEY 8(f) N1/N2 and BASELINE's bf16 config, for the factorised cell of rnn.py:783-798).
+The layout flags change WHERE a row lives, not the arithmetic: outputs equal the time-major run bit for bit.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fastgrnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from kws_amd import FastGRNNCUDA, fastgrnn_cuda
+DEV = "cuda:0"
+SAVE_PREACT, BATCH_MAJOR, X_BFT, GRAD_LAST, HS_LAST = 4, 16, 128, 256, 512
+F, H = 32, 256
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _params(rw, ru, seed=4):
+    p = O.make_params(F, H, rw, ru, dtype=np.float32, seed=seed, randomize_scalars=True)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    return p, P
+
+
+def _run(P, x, G, h0, flags, gate=0):
+    outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, gate,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+    gr = fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[2], h0,
+                                       P["w1"], P["w2"], P["u1"], P["u2"], gate, flags=flags,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    return list(outs), list(gr)
+
+
+@pytest.mark.parametrize("B,rw,ru,bf16", [(37, 16, 16, False), (64, 16, 16, False), (48, 8, 12, False), (1, 16, 16, False),
+                                          (37, 16, 16, True), (64, 16, 8, True)])
+def test_batch_major_and_bft_layouts_equal_time_major(B, rw, ru, bf16):
+    T = 23
+    _, P = _params(rw, ru)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(9 + B)
+    x = torch.randn(T, B, F, generator=g).to(dt).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(dt).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    for fl in (BATCH_MAJOR, X_BFT, BATCH_MAJOR | X_BFT):
+        for direction in (0, 1):
+            assert fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, 0, dtype=dt, direction=direction, flags=SAVE_PREACT | fl) == 2
+    o_t, g_t = _run(P, x, G, h0, SAVE_PREACT)
+    tb = lambda a: a.transpose(0, 1).contiguous()
+    for fl in (BATCH_MAJOR, X_BFT, BATCH_MAJOR | X_BFT):
+        bm, bft = bool(fl & BATCH_MAJOR), bool(fl & X_BFT)
+        xi = x.permute(1, 2, 0).contiguous() if bft else (tb(x) if bm else x)
+        o, gr = _run(P, xi, tb(G) if bm else G, h0, SAVE_PREACT | fl)
+        for a, b in zip(o_t[:2], o[:2]):                                   # hs, pre-activation
+            assert torch.equal(a, b.transpose(0, 1) if bm else b), fl
+        assert torch.equal(o_t[2], o[2])                                   # the rank-space vector is always time-major
+        dx = gr[0].permute(2, 0, 1) if bft else (gr[0].transpose(0, 1) if bm else gr[0])
+        assert gr[0].shape == xi.shape and torch.equal(g_t[0], dx), fl
+        for k in (1, 2, 3, 4, 5, 8, 9, 10, 11):
+            assert torch.equal(g_t[k], gr[k]), (fl, k)
+
+
+@pytest.mark.parametrize("B,bf16,batch_major", [(64, False, False), (37, False, False), (48, True, False), (37, False, True)])
+def test_grad_last_and_hs_last(B, bf16, batch_major):
+    """GRAD_LAST: the [B,H] gradient of the last state equals the dense, zero-padded [T,B,H] gradient bit for bit.
+    HS_LAST: the [B,H] output equals the last row of the full forward (a separately compiled kernel variant:
+    fp32 rounding, one bf16 ulp for bf16 sequences)."""
+    T, r = 19, 16
+    _, P = _params(r, r, seed=8)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(31 + B)
+    x = torch.randn(T, B, F, generator=g).to(dt).to(DEV)
+    gl = torch.randn(B, H, generator=g).to(dt).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    base = SAVE_PREACT | (BATCH_MAJOR if batch_major else 0)
+    if batch_major:
+        x = x.transpose(0, 1).contiguous()
+    G = torch.zeros((B, T, H) if batch_major else (T, B, H), dtype=dt, device=DEV)
+    (G[:, -1] if batch_major else G[-1]).copy_(gl)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, 0, dtype=dt, direction=1, flags=base | GRAD_LAST) == 2
+    o, g_dense = _run(P, x, G, h0, base)
+    gr = fastgrnn_cuda.backward_unroll(gl, x, o[0], P["zeta"], P["nu"], P["w"], P["u"], o[1], o[2], h0,
+                                       P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=base | GRAD_LAST,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    for k in (0, 1, 2, 3, 4, 5, 8, 9, 10, 11):
+        assert torch.equal(g_dense[k], gr[k]), k
+    fl = HS_LAST | (BATCH_MAJOR if batch_major else 0)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, 0, dtype=dt, direction=0, flags=fl) == 2
+    hl = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                      P["w1"], P["w2"], P["u1"], P["u2"], want_gates=False, flags=fl)[0]
+    last = o[0][:, -1] if batch_major else o[0][-1]
+    assert hl.shape == (B, H) and hl.dtype == dt
+    assert float((hl.float() - last.float()).abs().max()) <= (2.0 ** -7 if bf16 else 2e-6)
+    with pytest.raises(RuntimeError):                  # HS_LAST saves nothing for a backward
+        fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                     P["w1"], P["w2"], P["u1"], P["u2"], flags=fl | SAVE_PREACT)
+
+
+@pytest.mark.parametrize("B,rw,ru", [(64, 16, 16), (37, 16, 16), (48, 8, 8)])
+def test_bf16_sequences_fp32_master_grads_lowrank(B, rw, ru):
+    """x, hs, grad_hs, d_x bf16 in HBM; state, factors, saved tensors and every parameter gradient fp32.  Against the
+    fp64 oracle on the SAME rounded tensors (as the dense test in test_hip_parity.py)."""
+    T = 31
+    rng = np.random.default_rng(77 + B)
+    p, P = _params(rw, ru, seed=23)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)
+    x_bf = bf(rng.standard_normal((T, B, F)).astype(np.float32))
+    G_bf = bf(rng.standard_normal((T, B, H)).astype(np.float32))
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, 0, dtype=torch.bfloat16, direction=1, flags=SAVE_PREACT) == 2
+    o, gr = _run(P, x_bf.to(DEV), G_bf.to(DEV), _t(h0), SAVE_PREACT)
+    hs, pre = o[0], o[1]
+    assert hs.dtype == torch.bfloat16 and pre.dtype == torch.float32 and gr[0].dtype == torch.bfloat16
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = x_bf.to(torch.float64).numpy(); G64 = G_bf.to(torch.float64).numpy(); h64 = h0.astype(np.float64)
+    hs_o, zs_o, cs_o = O.unroll_forward(x64, p64, h64)
+    hs_k = hs.to(torch.float64).cpu().numpy()
+    assert (np.abs(hs_k - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 2.0 ** -8 + 1e-5
+    # backward: the kernel sees the ROUNDED hs as h_prev; oracle on the same tensors, gates from the saved pre-activation
+    pre_k = pre.cpu().numpy().astype(np.float64)
+    z_k = 1.0 / (1.0 + np.exp(-(pre_k + p64["bias_gate"]))); c_k = np.tanh(pre_k + p64["bias_update"])
+    g_o = O.unroll_backward(G64, x64, hs_k, z_k, c_k, p64, h64, diagnostics=True)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: v for n, v in zip(names, gr) if v.numel()}
+    dx = g.pop("d_x").to(torch.float64).cpu().numpy()
+    ref = g_o.pop("d_x")
+    assert (np.abs(dx - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2.0 ** -8 + 2e-5
+    for k, v in g_o.items():
+        if k.startswith("_"):
+            continue
+        err = float(np.abs(g[k].cpu().numpy().reshape(v.shape) - v).max())
+        lim = 2e-5 * max(1.0, float(np.abs(v).max()))
+        if k in ("d_zeta", "d_nu"):
+            lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
+        assert err <= lim, (k, err, lim)
+
+
+@pytest.mark.parametrize("kind", ["batch_first", "bft_view", "bf16", "rank8"])
+def test_module_lowrank_uses_the_layout_flags(kind):
+    """FastGRNNCUDA with factorised weights: batch_first input, the trainer's permuted [B,F,T] view and bf16 frames all
+    reach kernel path 2 in place; the results equal a plain time-major fp32/bf16 run of the same module."""
+    T, B = 17, 40
+    r = 8 if kind == "rank8" else 16
+    torch.manual_seed(3)
+    m = FastGRNNCUDA(F, H, wRank=r, uRank=r, batch_first=(kind == "batch_first"), device=DEV)
+    ref = FastGRNNCUDA(F, H, wRank=r, uRank=r, device=DEV)
+    ref.load_state_dict(m.state_dict())
+    dt = torch.bfloat16 if kind == "bf16" else torch.float32
+    x = torch.randn(T, B, F, device=DEV).to(dt)
+    x_ref = x.clone().requires_grad_(True)
+    out_ref = ref(x_ref)
+    out_ref.float().square().mean().backward()
+    if kind == "batch_first":
+        xi = x.transpose(0, 1).contiguous().requires_grad_(True)
+        out = m(xi).transpose(0, 1)
+    elif kind == "bft_view":
+        base = x.permute(1, 2, 0).contiguous().requires_grad_(True)       # the loader's [B,F,T]
+        xi = base
+        out = m(base.permute(2, 0, 1))
+    else:
+        xi = x.clone().requires_grad_(True)
+        out = m(xi)
+    out.float().square().mean().backward()
+    assert torch.equal(out, out_ref)
+    gx = xi.grad.transpose(0, 1) if kind == "batch_first" else (xi.grad.permute(2, 0, 1) if kind == "bft_view" else xi.grad)
+    assert torch.equal(gx, x_ref.grad)
+    for (n, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+        assert torch.equal(a.grad, b.grad), n

@@ -195,15 +195,18 @@ def test_preact_mode_vs_oracle(B):
     _check_grads(g, g_o, 2e-5, "preact")
 
 
-@pytest.mark.parametrize("T,B,gate", [(1, 16, 0), (6, 37, 0), (7, 64, 0), (9, 130, 0), (4, 21, 1), (5, 48, 2)])
-def test_lowrank_preact_contract_vs_oracle(T, B, gate):
-    """config-(4) shape (H=256, wRank=uRank=16) under FLAG_SAVE_PREACT: the forward saves the
-    pre-activation and the rank-space vector [U1.h | W1.x]; the backward is the split-precision
-    low-rank scan + split-K weight-gradient GEMMs.  All twelve outputs against the fp64 oracle."""
-    F, H, r = 32, 256, 16
+@pytest.mark.parametrize("T,B,gate,rw,ru", [(1, 16, 0, 16, 16), (6, 37, 0, 16, 16), (7, 64, 0, 16, 16), (9, 130, 0, 16, 16),
+                                            (4, 21, 1, 16, 16), (5, 48, 2, 16, 16), (7, 37, 0, 8, 8), (6, 64, 0, 16, 8),
+                                            (5, 33, 2, 5, 12), (4, 16, 0, 1, 1)])
+def test_lowrank_preact_contract_vs_oracle(T, B, gate, rw, ru):
+    """config-(4) shape (H=256, wRank=uRank=16) and the other ranks up to 16 (rnn.py:783-798; zero-extended to 16 in
+    the kernels) under FLAG_SAVE_PREACT: the forward saves the pre-activation and the rank-space vector
+    [U1.h | W1.x]; the backward is the split-precision low-rank scan + split-K weight-gradient GEMMs.  All twelve
+    outputs against the fp64 oracle."""
+    F, H = 32, 256
     GN = ["sigmoid", "relu", "tanh"]
     rng = np.random.default_rng(300 + T + B)
-    p = O.make_params(F, H, r, r, dtype=np.float32, seed=17, randomize_scalars=True)
+    p = O.make_params(F, H, rw, ru, dtype=np.float32, seed=17, randomize_scalars=True)
     if gate == 1:      # relu gate: keep z around 0..1 (see test_seeded_vs_oracle_fp32)
         for k in ("w1", "w2", "u1", "u2"):
             p[k] = (0.55 * p[k]).astype(np.float32)     # the product of two factors scales by 0.3
@@ -214,12 +217,15 @@ def test_lowrank_preact_contract_vs_oracle(T, B, gate):
     P = _param_tensors(p)
     xt, ht, Gt = _t(x), _t(h0), _t(G)
     SAVE_PREACT = 4
-    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, gate, direction=1, flags=SAVE_PREACT) == 2
-    assert fastgrnn_cuda.kernel_path(T, B, F, H, r, r, gate, direction=1) != 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate, direction=1, flags=SAVE_PREACT) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate, direction=1) != 2
     hs, pre, m = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"],
                                               P["nu"], ht, gate, P["w1"], P["w2"], P["u1"], P["u2"],
                                               flags=SAVE_PREACT)
-    assert m.shape == (T, B, 2 * r)
+    assert m.shape == (T * B, 32)                 # [U1.h | W1.x], each zero-extended to 16 columns, time-major
+    m4 = m.cpu().numpy().reshape(T, B, 32)
+    assert not m4[..., ru:16].any() and not m4[..., 16 + rw:].any()
+    m_k = np.concatenate([m4[..., :ru], m4[..., 16:16 + rw]], -1)
     outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, m, ht,
                                          P["w1"], P["w2"], P["u1"], P["u2"], gate, flags=SAVE_PREACT,
                                          bias_gate=P["bias_gate"], bias_update=P["bias_update"])
@@ -228,10 +234,10 @@ def test_lowrank_preact_contract_vs_oracle(T, B, gate):
     hs_o, zs_o, cs_o = O.unroll_forward(x64, p64, h64, gate=GN[gate])
     hprev = np.concatenate([h64[None], hs_o[:-1]], 0)
     m_o = np.concatenate([hprev @ p64["u1"].T, x64 @ p64["w1"].T], -1)
-    pre_o = m_o[..., r:] @ p64["w2"].T + m_o[..., :r] @ p64["u2"].T
+    pre_o = m_o[..., ru:] @ p64["w2"].T + m_o[..., :ru] @ p64["u2"].T
     rel = lambda a, ref: (np.abs(a - ref) / np.maximum(1.0, np.abs(ref))).max()
     assert rel(hs.cpu().numpy(), hs_o) <= 1e-5
-    assert rel(m.cpu().numpy(), m_o) <= 1e-5
+    assert rel(m_k, m_o) <= 1e-5
     assert rel(pre.cpu().numpy(), pre_o) <= 1e-5
     g_o = O.unroll_backward(G.astype(np.float64), x64, hs_o, zs_o, cs_o, p64, h64, gate=GN[gate], diagnostics=True)
     tol = 2e-5
@@ -544,8 +550,8 @@ def test_batch_major_layout_equals_time_major(B, preact):
     assert g_b[0].shape == (B, T, F) and torch.equal(g_t[0], g_b[0].transpose(0, 1))
     for a, b in zip(g_t[1:8], g_b[1:8]):
         assert torch.equal(a, b)
-    # not available off the dense split-precision path: the caller transposes instead
-    assert fastgrnn_cuda.kernel_path(T, B, F, 256, 16, 16, 0, direction=0, flags=base | BATCH_MAJOR) != 2
+    # not available off the split-precision path: the caller transposes instead
+    assert fastgrnn_cuda.kernel_path(T, B, 20, 100, 0, 0, 0, direction=0, flags=base | BATCH_MAJOR) != 2
     with pytest.raises(RuntimeError):
         fastgrnn_cuda.forward_unroll(x.transpose(0, 1).contiguous(), P["w"], P["u"], P["bias_gate"], P["bias_update"],
                                      P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"],
@@ -1013,24 +1019,3 @@ def test_model_tail_last_state_plus_head_matches_the_reference_chain():
         scale = max(1e-12, float(g_ref[n].abs().max()))
         assert float((p_.grad - g_ref[n]).abs().max()) / scale <= 2e-5, n
     assert float((x2.grad - x1.grad).abs().max()) / max(1e-12, float(x1.grad.abs().max())) <= 2e-5
-
-
-@pytest.mark.parametrize("B", [32, 21])
-def test_lowrank_forward_wave_shapes_agree(B):
-    """The low-rank forward runs 8 waves of 32 units (default) or 4 waves of 64 (FLAG_FWD_4WAVE, the first shape,
-    kept for A/B): same arithmetic per element, different order of the eight / four rank-space partial sums, so
-    hs, the pre-activation and the rank-space vector agree to fp32 rounding."""
-    T, F, H, r = 15, 32, 256, 16
-    p = O.make_params(F, H, r, r, seed=51, randomize_scalars=True)
-    P = _param_tensors(p)
-    g = torch.Generator().manual_seed(52)
-    x = torch.randn(T, B, F, generator=g).to(DEV)
-    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
-    args = (x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])
-    for base in (0, 4):
-        a = fastgrnn_cuda.forward_unroll(*args, flags=base)
-        b = fastgrnn_cuda.forward_unroll(*args, flags=base | 8)
-        assert len(a) == len(b)
-        for k, (u_, v_) in enumerate(zip(a, b)):
-            scale = max(1.0, float(u_.abs().max()))
-            assert float((u_ - v_).abs().max()) / scale <= 2e-5, (base, k)
