@@ -81,18 +81,20 @@ typedef enum fastgrnn_nonlinearity {
  * h_prime_t from it and therefore needs params->bias_gate / bias_update.  Saves one [T,B,H] write
  * and one read per step against the reference operator's (z_s, h_prime_s) pair. */
 #define FASTGRNN_FLAG_SAVE_PREACT 4u
-/* A/B only: run the dense split-precision forward in its older 4-wave shape (one wave per SIMD, two
- * row tiles per wave) instead of the default 8-wave one.  Same results to fp32 rounding. */
+/* A/B only: run the dense H=128/F=32 split-precision forward in its older 4-wave shape (one wave per SIMD, two
+ * row tiles per wave) instead of the default 8-wave one.  Same results to fp32 rounding.  Ignored by the other
+ * shapes of kernel path 2. */
 #define FASTGRNN_FLAG_FWD_4WAVE 8u
 /* Batch-major sequences (the trainer's batch_first layout, rnn.py:812-813,823-825): x, hs, z_s, c_s,
- * grad_hs and d_x are [B,T,.] instead of [T,B,.]; h0/d_h0 stay [B,H].  Kernel path 2, dense operands
- * only -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the caller transposes as the reference
- * does.  Removes the transpose(0,1).contiguous() copies around the operator. */
+ * grad_hs and d_x are [B,T,.] instead of [T,B,.]; h0/d_h0 stay [B,H].  Kernel path 2 (dense H=128 and the
+ * low-rank H=256 scans; not the dense H=256 ones) -- anything else answers FASTGRNN_ERR_UNSUPPORTED and the
+ * caller transposes as the reference does.  Removes the transpose(0,1).contiguous() copies around the operator. */
 #define FASTGRNN_FLAG_BATCH_MAJOR 16u
 /* x and d_x are [B,F,T]: what the trainer's data loader delivers and permute(2,0,1)s into a [T,B,F] VIEW
  * (trainClassifier.py:204,299) that the reference then copies with .contiguous() (rnn.py:910).  Independent
- * of FASTGRNN_FLAG_BATCH_MAJOR (which then only governs hs, the saved tensor and grad_hs).  Kernel path 2,
- * dense H=128/F=32, 8-wave kernels (forward; backward under FASTGRNN_FLAG_SAVE_PREACT). */
+ * of FASTGRNN_FLAG_BATCH_MAJOR (which then only governs hs, the saved tensor and grad_hs).  Kernel path 2:
+ * dense H=128/F=32 (read and written in place) and the low-rank H=256/F=32 scans (through a time-major copy in
+ * the workspace, which is what the reference's .contiguous() makes); backward under FASTGRNN_FLAG_SAVE_PREACT. */
 #define FASTGRNN_FLAG_X_BFT 128u
 /* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
  * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
@@ -103,7 +105,8 @@ typedef enum fastgrnn_nonlinearity {
  *              kernel read: 2 x 208 MB at B=4096).  hs, the saved tensors and every output keep their shapes.
  *   HS_LAST    forward_unroll (inference: z_s must be NULL): hs is [B,H] and receives h_T only (a separately
  *              compiled kernel variant: equal to the last row of the full forward to fp32 rounding).
- * Both: dense H=128/F=32 (8-wave kernels), any sequence layout; FASTGRNN_ERR_UNSUPPORTED otherwise. */
+ * Both: dense H=128 (F = 32 and the wide-input layers) and low-rank H=256/F=32, any sequence layout;
+ * FASTGRNN_ERR_UNSUPPORTED otherwise. */
 #define FASTGRNN_FLAG_GRAD_LAST 256u
 #define FASTGRNN_FLAG_HS_LAST 512u
 
@@ -148,10 +151,27 @@ const char *fastgrnn_hip_status_string(int status);
  * 1 = fp32-MFMA scan (v_mfma_f32_16x16x4_f32; 16 utterances per workgroup, U in registers),
  * 2 = split-precision scan: every fp32 operand as three exact bf16 planes, six
  *     v_mfma_f32_16x16x32_bf16 terms per product, fp32 accumulation (error O(2^-24)).
- * direction: 0 forward, 1 backward.  Pure function of the descriptor. */
+ * direction: 0 forward, 1 backward.  Pure function of the descriptor.
+ *
+ * Shapes on path 2 (fp32 or bf16 sequences unless noted; everything else runs on paths 1 / 0, 20-30x slower at
+ * B = 4096 -- ask this function before assuming):
+ *   dense  H=128, F=32            every gate; update tanh or quantTanh (quantTanh: fp32, SAVE_PREACT backward);
+ *                                 all layout flags.  Backward with the reference's (z_s, h_prime_s) tensors for the
+ *                                 sigmoid / relu / tanh gates, otherwise under FASTGRNN_FLAG_SAVE_PREACT.
+ *   dense  H=128, F=64/128/256    (the reference's second layer) fp32; time- or batch-major; last-state flags.
+ *   dense  H=256, F=32            (the reference's first layer) fp32, time-major, gates sigmoid / relu / tanh.
+ *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are
+ *                                 zero-extended to 16 inside the kernels): gates sigmoid / relu / tanh; all layout
+ *                                 flags; backward under FASTGRNN_FLAG_SAVE_PREACT only.  Ranks above 16 and cells
+ *                                 with only one of W, U factorised (rnn.py:783-798) run on the generic scan.
+ * Under FASTGRNN_FLAG_SAVE_PREACT a factorised forward also writes, through c_s, the rank-space vector
+ * [U1.h_{t-1} | W1.x_t] as a time-major fp32 [T*B, 32] tensor (each half zero-extended to 16 columns) that the
+ * backward takes back through c_s. */
 int fastgrnn_hip_kernel_path(const fastgrnn_desc *d, int direction);
 
-/* Workspace sizes in bytes (0 is a valid answer).  Workspace must be 256-B aligned. */
+/* Workspace sizes in bytes (0 is a valid answer).  Workspace must be 256-B aligned.  The forward answer covers a
+ * call without auxiliary outputs; dense H=128 layers with F > 32 park the frame product X.W^T in z_s / c_s when
+ * the caller passes them and then accept workspace == NULL. */
 size_t fastgrnn_hip_forward_workspace_bytes(const fastgrnn_desc *d);
 size_t fastgrnn_hip_backward_workspace_bytes(const fastgrnn_desc *d);
 
