@@ -225,6 +225,11 @@ int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void *h_last, 
                            void *d_h_last, void *d_fc_w, void *d_fc_b,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* Test hook, not part of the reference boundary: one launch that leaves `pattern` in every CU's LDS and vector
+ * registers (on-chip state is not cleared between kernels).  tests/test_hip_state_independence.py runs it before the
+ * operators with a NaN pattern: results must not change, i.e. no kernel reads LDS or registers it did not write. */
+int fastgrnn_hip_debug_poison_cu_state(uint32_t pattern, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,8 @@ def load():
     lib.fastgrnn_hip_forward.argtypes = [DP, PP, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.fastgrnn_hip_backward.restype = i32
     lib.fastgrnn_hip_backward.argtypes = [DP, PP, vp, vp, vp, vp, vp, GP, vp, sz, vp]
+    lib.fastgrnn_hip_debug_poison_cu_state.restype = i32
+    lib.fastgrnn_hip_debug_poison_cu_state.argtypes = [C.c_uint32, vp]
     lib.fastgrnn_hip_head_workspace_bytes.restype = sz
     lib.fastgrnn_hip_head_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.fastgrnn_hip_head_xent.restype = i32

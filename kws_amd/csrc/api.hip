@@ -164,4 +164,8 @@ int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void* h_last, 
                    reinterpret_cast<hipStream_t>(stream));
 }
 
+int fastgrnn_hip_debug_poison_cu_state(uint32_t pattern, void* stream) {
+  return debug_poison(pattern, reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -116,4 +116,7 @@ size_t head_ws_bytes(int B, int H, int C);
 int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const void* fc_b, const void* labels,
               void* loss, void* logp, void* d_h, void* d_w, void* d_b, void* ws, hipStream_t s);
 
+// test hook (kernels_debug.hip): fill every CU's LDS and vector registers with a bit pattern
+int debug_poison(unsigned pattern, hipStream_t s);
+
 }  // namespace fastgrnn

@@ -605,6 +605,10 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   constexpr unsigned ESZ = BF ? 2u : 4u;             // bytes per sequence element (x, hs, grad_hs)
   const unsigned lane_e = (unsigned)bc * (unsigned)rsB * H + n0;          // element offset of this lane inside a step's rows
   const unsigned lane_bh = (unsigned)bc * H + n0;                         // ... inside a [B,H] tensor
+  // NOX: byte offset of this lane's d_pre values inside a step's rows and the byte stride between steps (0 for the sink)
+  const unsigned dp_step = (NOX && valid) ? (unsigned)rsT * H * 4u : 0u;
+  const unsigned dp_off = !NOX ? 0u : (valid ? ((unsigned)b * (unsigned)rsB * H + n0) * 4u
+                                             : (((unsigned)Tn * (unsigned)B + i) * H + n0) * 4u);
   const unsigned lane_x = NOX ? 0u : (xbft ? ((unsigned)xbc * F + xf) * (unsigned)Tn : (unsigned)xbc * (unsigned)rsB * F + xf);
   auto ldg4 = [](const void* base, unsigned byte_off) __attribute__((always_inline)) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -704,8 +708,14 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     unsigned char* im = &S.img[t & 3][0];
     put4(im + OFF_DP, PLANE_H, my_row_h, dpv);
     put4(im + OFF_HP, PLANE_H, my_row_h, e.h);
-    if (NOX) {                                       // d_pre_t for the weight-gradient / d_x GEMMs (fp32, [T,B,H] layout of hs)
-      if (valid) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(d_x + (size_t)t * rsT * H) + ((unsigned)b * (unsigned)rsB * H + n0) * 4u) = dpv;
+    if (NOX) {
+      // d_pre_t for the weight-gradient / d_x GEMMs (fp32, [T,B,H] layout of hs).  EVERY lane stores, without a
+      // branch: lanes beyond a ragged batch write to the 16 sink rows behind the T*B rows (step stride 0).  The
+      // first form, "if (valid) store" -- an exec-masked block with its own address arithmetic between the plane
+      // writes above and the next step's loads -- gave rare wrong results in whole workgroups (all of them full
+      // ones) that went away with idle cycles on either side of the block; the cause is not understood, so the
+      // steady state of this scan has no conditional code around memory instructions at all.
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(d_x) + (size_t)t * dp_step + dp_off) = dpv;
     } else {
       unsigned short s0, s1, s2;
       split_one(e.xv, s0, s1, s2);
@@ -967,14 +977,15 @@ __global__ __launch_bounds__(1024) void reduce_slabs_split(int nwg, const float*
 // the scans keep the recurrence only, the frame products are batched GEMMs (kernels_gemm.hip).
 bool dense_wide_shape(const fastgrnn_desc& d) {
   return d.w_rank == 0 && d.u_rank == 0 && d.H == 128 && (d.F == 64 || d.F == 128 || d.F == 256) &&
-         (double)d.T * d.B * d.F * 4.0 < 4294967296.0;       // 32-bit byte offsets inside a tensor (see split_supported)
+         // 32-bit byte offsets inside a tensor (see split_supported), the d_pre workspace's 16 sink rows included
+         ((double)d.T * d.B + 16.0) * (d.F > 128 ? d.F : 128) * 4.0 < 4294967296.0;
 }
 struct WideBwdWs { size_t slabs, dpre, tn, total; };
 WideBwdWs wide_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   WideBwdWs L; size_t o = 0;
   L.slabs = o; o += align256(nwg * SLAB * 4);
-  L.dpre = o; o += align256(TB * 128 * 4);
+  L.dpre = o; o += align256((TB + 16) * 128 * 4);    // + 16 sink rows for the lanes beyond a ragged batch
   L.tn = o; o += tn_gemm_big_ws(TB, 128, d.F);
   L.total = o;
   return L;

@@ -95,10 +95,38 @@ _Z5cleanv:
 
 NOT_SCANNED = CLEAN_AFTER_COMPLETION_READ + "\t.amdhsa_kernel _Z7missingv\n"
 
+# the C input is fetched like A and B: a reload of it behind the MFMA is a hazard too
+HAZARD_C_OPERAND = """
+_Z4cregv:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[12:15]
+\tds_read_b128 v[12:15], v20
+\tv_add_f32 v30, v0, v0
+\ts_endpgm
+.Lfunc_end0:
+\t.amdhsa_kernel _Z4cregv
+"""
+
+# a result register that something else has overwritten no longer proves anything: MFMA 1's result v[0:3] is consumed
+# only as the C input of MFMA 2, then reloaded; the read of v0 that follows is a read of the LOAD, not of the pipe
+HAZARD_STALE_RESULT = """
+_Z5stalev:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], 0
+\tv_mfma_f32_16x16x32_bf16 v[16:19], v[4:7], v[8:11], v[0:3]
+\tds_read_b128 v[0:3], v20
+\tv_add_f32 v30, v0, v0
+\tds_read_b128 v[4:7], v21
+\tv_add_f32 v31, v16, v16
+\ts_endpgm
+.Lfunc_end0:
+\t.amdhsa_kernel _Z5stalev
+"""
+
 
 @pytest.mark.parametrize("asm,bad", [(HAZARD_FAR, True), (HAZARD_TAKEN_ARM, True),
-                                     (CLEAN_AFTER_COMPLETION_READ, False), (NOT_SCANNED, True)],
-                         ids=["beyond_any_window", "branch_target_arm", "completion_read", "kernel_not_scanned"])
+                                     (CLEAN_AFTER_COMPLETION_READ, False), (NOT_SCANNED, True),
+                                     (HAZARD_C_OPERAND, True), (HAZARD_STALE_RESULT, True)],
+                         ids=["beyond_any_window", "branch_target_arm", "completion_read", "kernel_not_scanned",
+                              "c_operand", "stale_result_register"])
 def test_scanner_on_synthetic_streams(tmp_path, asm, bad):
     """The scanner itself: a reload 120 instructions behind the MFMA and one on the taken arm of a conditional
     branch are both found (the round-1 scanner looked 40 instructions ahead on the fall-through path only); a

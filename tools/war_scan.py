@@ -19,6 +19,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 path = args[0]
 MAX_STEPS = int(args[1]) if len(args) > 1 else 6000
 LIST_ONLY = "--list" in sys.argv
+NO_PRUNE = "--no-prune" in sys.argv      # follow both arms of every branch (reports paths the scalar flags rule out)
+ONLY = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")), None)      # kernel-name substring
 TRACE = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--trace=")), None)   # kernel-name substring
 LOADS = ("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")
 STORES = ("global_store", "ds_write", "ds_store", "buffer_store", "scratch_store", "flat_store", "v_cmp", "v_cmpx",
@@ -95,8 +97,10 @@ def parse_kernel(lines):
         if op.startswith("v_mfma") or op.startswith("v_smfmac"):
             x.kind = "mfma"
             x.dst = regs(ops[0])
-            x.ab = regs(ops[1]) | regs(ops[2])
-            x.src = x.ab | (regs(ops[3]) if len(ops) > 3 else set())
+            # every register the matrix pipe fetches: A, B and the C input (a C that is the result of an older MFMA
+            # is forwarded inside the pipe, but one written by the VALU -- the chain's z*g -- is fetched like A and B)
+            x.ab = regs(ops[1]) | regs(ops[2]) | (regs(ops[3]) if len(ops) > 3 else set())
+            x.src = set(x.ab)
         elif op.startswith(LOADS):
             x.kind = "load"
             x.dst = regs(ops[0]) if ops else set()
@@ -226,7 +230,7 @@ def scan_kernel(ins, block_starts):
                     continue
                 if k == "fork":
                     take, fall = True, True
-                    if x.cond is not None and "vcc" in known:
+                    if x.cond is not None and "vcc" in known and not NO_PRUNE:
                         nz = known["vcc"] == 1
                         take = nz if x.cond == "vccnz" else not nz
                         fall = not take
@@ -242,6 +246,11 @@ def scan_kernel(ins, block_starts):
                     continue
                 if x.src & done:
                     break                            # completion read: the matrix pipe has drained past MFMA i
+                if x.dst & done:
+                    # the register no longer holds an MFMA result once something else has written it: a later read of
+                    # it proves nothing about the matrix pipe (a result consumed only as the C operand of a younger
+                    # MFMA and then reused as a load destination would otherwise pass for a completion read)
+                    done = done - x.dst
                 if k == "load" and (x.dst & ab):
                     found = (dist, m.text, x.text)
                     if TRACE_ON[0]:
@@ -290,6 +299,8 @@ if LIST_ONLY:
 
 bad_total = 0
 for name, lines in kernels.items():
+    if ONLY and ONLY not in name:
+        continue
     ins, block_starts = parse_kernel(lines)
     TRACE_ON[0] = bool(TRACE) and TRACE in name
     n_mfma, hits, unbounded = scan_kernel(ins, block_starts)
@@ -299,7 +310,7 @@ for name, lines in kernels.items():
         print("%-50s mfma %4d  load-behind-mfma pairs %3d%s%s" % (
             short, n_mfma, len(hits), ("   closest +%d" % min(h[0] for h in hits)) if hits else "",
             ("   UNBOUNDED paths %d" % unbounded) if unbounded else ""))
-        for h in sorted(hits)[:3]:
+        for h in sorted(hits)[:(40 if ONLY else 3)]:
             print("      +%d  %s   <-   %s" % h)
         if spills:
             print("      SPILLS IN LOOP %d, e.g. %s: %s" % (len(spills), spills[0][0], spills[0][1]))
