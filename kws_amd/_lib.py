@@ -35,7 +35,7 @@ EXPORTS = (
     "fastgrnn_hip_forward_workspace_bytes", "fastgrnn_hip_backward_workspace_bytes",
     "fastgrnn_hip_forward_unroll", "fastgrnn_hip_backward_unroll",
     "fastgrnn_hip_forward", "fastgrnn_hip_backward",
-    "fastgrnn_hip_head_workspace_bytes", "fastgrnn_hip_head_xent",
+    "fastgrnn_hip_head_workspace_bytes", "fastgrnn_hip_head_xent", "fastgrnn_hip_debug_poison_cu_state",
 )
 
 
