@@ -72,9 +72,13 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
   const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
   if (s_begin >= s_end) return;                   // (whole workgroup: no barrier has been passed)
 
-  f32x4 va[VPT];
-  uint2 vraw[VPT];                                // bf16 input: four values per 8 bytes, unpacked at publish time
-  auto load_stage = [&](size_t st) __attribute__((always_inline)) {
+  // two register sets: a stage's rows are requested two stages ahead (see tn_gemm_big)
+  struct Stage {
+    f32x4 va[VPT];
+    uint2 vraw[VPT];                              // bf16 input: four values per 8 bytes, unpacked at publish time
+  };
+  auto load_stage = [&](size_t st, Stage& S) __attribute__((always_inline)) {
+    f32x4 (&va)[VPT] = S.va; uint2 (&vraw)[VPT] = S.vraw;
     const size_t r0 = st * RG_ROWS;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
       else va[j] = ok ? ld4(reinterpret_cast<const float*>(Av) + e) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto publish = [&](int buf) __attribute__((always_inline)) {
+  auto publish = [&](int buf, const Stage& S) __attribute__((always_inline)) {
+    const f32x4 (&va)[VPT] = S.va; const uint2 (&vraw)[VPT] = S.vraw;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       const int idx = tid + 512 * j, row = idx / (K / 4), c4 = idx % (K / 4);
@@ -101,13 +106,14 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
     }
   };
 
-  load_stage(s_begin);
-  publish(0);
+  Stage S0, S1;
+  load_stage(s_begin, S0);
+  publish(0, S0);
   __syncthreads();
-  if (s_begin + 1 < s_end) load_stage(s_begin + 1);
+  if (s_begin + 1 < s_end) load_stage(s_begin + 1, S0);
+  if (s_begin + 2 < s_end) load_stage(s_begin + 2, S1);
 
-  int buf = 0;
-  for (size_t st = s_begin; st < s_end; ++st, buf ^= 1) {
+  auto stage = [&](size_t st, int buf, Stage& Snext) __attribute__((always_inline)) {
     const size_t r0 = st * RG_ROWS;
     // ---- this wave's tiles of the stage ----------------------------------------------------------------
 #pragma unroll
@@ -151,10 +157,18 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- next stage: planes into the other buffer, then the request for the stage after it -----------------
-    if (st + 1 < s_end) publish(buf ^ 1);
+    if (st + 1 < s_end) publish(buf ^ 1, Snext);
     lds_barrier();
-    if (st + 2 < s_end) load_stage(st + 2);
+    if (st + 3 < s_end) load_stage(st + 3, Snext);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    size_t st = s_begin;
+    for (; st + 1 < s_end; st += 2) {
+      stage(st, 0, S0);
+      stage(st + 1, 1, S1);
+    }
+    if (st < s_end) stage(st, 0, S0);
   }
   {                                               // the weight fragments stay allocated through the last stage
     float probe = 0.f;
@@ -211,8 +225,12 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   const size_t s_begin = (size_t)chunk * stages_per_wg;
   const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
 
-  f32x4 va[VA], vb[VB];
-  auto load_stage = [&](size_t st) __attribute__((always_inline)) {
+  // Two register sets: the rows of stage st + 2 are requested while stage st + 1 still waits in the other set, so a
+  // request is in flight for two iterations (one was not enough to keep HBM busy: the kernel ran at 2.9-3.7 TB/s
+  // with one workgroup's single stage in flight per CU).
+  struct Stage { f32x4 va[VA], vb[VB]; };
+  auto load_stage = [&](size_t st, Stage& S) __attribute__((always_inline)) {
+    f32x4 (&va)[VA] = S.va; f32x4 (&vb)[VB] = S.vb;
     const size_t r0 = st * TNB_STAGE;
 #pragma unroll
     for (int j = 0; j < VA; ++j) {
@@ -235,7 +253,8 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     *reinterpret_cast<uint2*>(p0 + plane_bytes + off) = q1;
     *reinterpret_cast<uint2*>(p0 + 2 * plane_bytes + off) = q2;
   };
-  auto publish = [&](int buf) __attribute__((always_inline)) {
+  auto publish = [&](int buf, const Stage& S) __attribute__((always_inline)) {
+    const f32x4 (&va)[VA] = S.va; const f32x4 (&vb)[VB] = S.vb;
 #pragma unroll
     for (int j = 0; j < VA; ++j) {
       const int idx = tid + 512 * j, row = idx / (MB / 4), c4 = idx % (MB / 4);
@@ -259,12 +278,15 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
     const unsigned trA = la0 + (8 * g + q) * ROWA + (mq * 32 + 4 * pp) * 2;
     const unsigned trB = lb0 + (8 * g + q) * ROWB + (nh * NH * 16 + 4 * pp) * 2;
-    load_stage(s_begin);
-    publish(0);
+    Stage S0, S1;
+    load_stage(s_begin, S0);
+    publish(0, S0);
     __syncthreads();
-    if (s_begin + 1 < s_end) load_stage(s_begin + 1);
-    int buf = 0;
-    for (size_t st = s_begin; st < s_end; ++st, buf ^= 1) {
+    if (s_begin + 1 < s_end) load_stage(s_begin + 1, S0);
+    if (s_begin + 2 < s_end) load_stage(s_begin + 2, S1);
+    // one stage: products from buffer buf, then the planes of stage st + 1 (waiting in Snext) into buffer buf ^ 1,
+    // then -- behind the barrier, i.e. behind every MFMA of the stage -- the request for stage st + 3 into Snext
+    auto stage = [&](size_t st, int buf, Stage& Snext) __attribute__((always_inline)) {
       const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * 3 * TNB_STAGE * ROWB;
       Frag3 Af[2];
 #pragma unroll
@@ -290,11 +312,19 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
         if (touch == 1.2345678e38f) part[0] = 1.f;
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (st + 1 < s_end) publish(buf ^ 1);
+      // (tried, same-run A/B: half of the waves publishing BEFORE their products, so that one wave's VALU split runs
+      // beside its SIMD partner's MFMAs -- for either pairing of the waves 9-16 % slower: 281 -> 309 us at N = 256)
+      if (st + 1 < s_end) publish(buf ^ 1, Snext);
       lds_barrier();
-      if (st + 2 < s_end) load_stage(st + 2);
+      if (st + 3 < s_end) load_stage(st + 3, Snext);
       __builtin_amdgcn_sched_barrier(0);
+    };
+    size_t st = s_begin;
+    for (; st + 1 < s_end; st += 2) {
+      stage(st, 0, S0);
+      stage(st + 1, 1, S1);
     }
+    if (st < s_end) stage(st, 0, S0);
   }
   // D row 4g + r of tile (mt, nt) is m = 16 mt + 4g + r, column n = 16 nt + (l & 15)
   float* pc = part + ((size_t)chunk * nblk + mblk) * MB * N;

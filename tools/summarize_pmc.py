@@ -3,6 +3,7 @@
     python tools/summarize_pmc.py gpurun_out/prof_<tag>  > profiles/<name>.md
 """
 import csv
+import re
 import glob
 import os
 import sys
@@ -10,13 +11,11 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("bwd_scan_split_w8", "fwd_scan_split_w8", "bwd_scan_lowrank_split", "fwd_scan_lowrank_split",
-              "tn_gemm_split", "tn_reduce", "reduce_lowrank_small",
-              "bwd_scan_split", "fwd_scan_split", "reduce_slabs_split", "bwd_scan_mfma", "fwd_scan_mfma",
-              "reduce_slabs", "fwd_scan_generic", "bwd_scan_generic"):
-        if k in name:
-            return k
-    return None
+    """kernel name with its template arguments ("bwd_scan_split_w8<0, true, false, false, false, false>"); None for
+    kernels that are not ours (torch fills, copies)"""
+    m = re.search(r"(?:fastgrnn::)(?:\(anonymous namespace\)::)?(\w+(?:<[^>]*>)?)\(", name) or \
+        re.search(r"(?:fastgrnn::)(?:\(anonymous namespace\)::)?(\w+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else None
 
 
 def main(root):
