@@ -806,6 +806,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     SPLIT_STAMP(0)
     constexpr bool MY_TURN = EVEN ? (ch == 0) : (ch == 1);
     const bool heavy = MY_TURN && (EVEN || t + 2 <= top);
+    // (tried: s_setprio 1 / 3 from here to the weight gradients, 0 there -- no change in three interleaved runs)
     const unsigned char* im = &S.img[t & 3][0];
     Frag3 dB[KS];
 #pragma unroll
