@@ -133,7 +133,8 @@ typedef struct fastgrnn_params {
  * for dense operands, d_w1,d_w2 / d_u1,d_u2 for factorised ones; the others are
  * ignored and may be NULL (reference returns torch::empty(0), .cu:221-224). */
 typedef struct fastgrnn_grads {
-  void *d_x;            /* [T,B,F] */
+  void *d_x;            /* [T,B,F]; may be NULL on kernel path 2 for dense H=256 and dense H=128 with F > 32 (the
+                           input's gradient is then not computed: one GEMM less -- a model's first layer) */
   void *d_bias_gate;    /* [1,H] */
   void *d_bias_update;  /* [1,H] */
   void *d_zeta;         /* [1,1] */

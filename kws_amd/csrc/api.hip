@@ -116,7 +116,9 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   if ((preact || (d->flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_GRAD_LAST)) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
   if (!grad_hs || !x || !hs || !z_s || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
-  if (!g->d_x || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)
+  // d_x may be NULL (the input's gradient is not wanted) where it is a GEMM of its own behind the scan
+  const bool dx_optional = pick_path(d, 1) == 2 && split_dx_optional(*d);
+  if ((!g->d_x && !dx_optional) || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)
     return FASTGRNN_ERR_NULL_POINTER;
   if (d->w_rank ? (!g->d_w1 || !g->d_w2) : !g->d_w) return FASTGRNN_ERR_NULL_POINTER;
   if (d->u_rank ? (!g->d_u1 || !g->d_u2) : !g->d_u) return FASTGRNN_ERR_NULL_POINTER;

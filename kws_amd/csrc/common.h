@@ -72,6 +72,7 @@ bool split_supported(const fastgrnn_desc& d, int direction);
 size_t split_forward_ws(const fastgrnn_desc& d);
 size_t split_backward_ws(const fastgrnn_desc& d);
 bool split_forward_ws_optional(const fastgrnn_desc& d);   // the forward workspace is only used when z_s is NULL
+bool split_dx_optional(const fastgrnn_desc& d);           // the backward accepts d_x == NULL (no input gradient)
 int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0,
                   void* hs, void* zs, void* cs, void* ws, hipStream_t s);
 int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x,

@@ -199,131 +199,6 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     }
   };
 
-  if constexpr (H16) {
-  // ---- fp16 path: software-pipelined step (tools/diag_h256.hip showed the first build spending 350 cycles per
-  // fragment batch on exposed LDS latency and pipe drains, with the SIMD's second wave queued behind all of it):
-  //   * the frame product W.x_{t+1} is issued at the END of step t, between publishing h_t and the barrier -- it
-  //     does not depend on h, so it fills the barrier wait instead of opening the next step;
-  //   * the state product walks the K-steps with two operand sets and two accumulator sets: while K-step k's MFMAs
-  //     execute, K-step k-1's accumulators are read (completion) and its set is refilled for K-step k+1.
-  __syncthreads();                                   // sbias staged, W planes written
-  publish_h(0);
-  publish_x(0, load_x(0));
-  if (Tn > 1) publish_x(1, load_x(1));
-  float xnext = load_x(Tn > 2 ? 2 : Tn - 1);         // frame t+2, published during step t
-  __syncthreads();
-  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 wxa[2], wxl[2];                              // W.x of the coming step: big / small terms
-  auto wx_issue = [&](int buf) __attribute__((always_inline)) {
-    Frag3 xB, Wl[2];
-    const unsigned char* xp = xpl + buf * 3 * PLX2;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) xB.p[p] = *reinterpret_cast<const u32x4*>(xp + p * PLX2 + i * ROWX2 + 16 * g);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) Wl[mt].p[p] = wfl[((wv * 2 + mt) * 3 + p) * 64 + l];
-    __builtin_amdgcn_sched_barrier(0);               // every fragment read issued before the first MFMA
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { wxa[mt] = z4; wxl[mt] = z4; mfma6_hl(Wl[mt], xB, wxa[mt], wxl[mt]); }   // .cu:356
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  wx_issue(0);
-  lds_barrier();                                     // every wave has read frame 0's planes: buffer 0 may take frame 2
-
-  f32x4 aux_prev[2] = {z4, z4};
-#ifdef FASTGRNN_DIAG_STAMPS
-  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
-#endif
-  struct KOps { u32x4 hi, lo; };
-  for (int t = 0; t < Tn; ++t) {
-    SPLIT_STAMP(0)
-    const int cur = t & 1, nxt = cur ^ 1;
-    const unsigned char* hp = hpl + cur * NPL * PLH2;
-    // W.x_t was issued before the barrier: reading its accumulators proves it has retired before any request below
-    // may reuse its operand registers
-    f32x4 wx[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) wx[mt] = wxa[mt] + wxl[mt];
-    asm volatile("" : "+v"(wx[0]), "+v"(wx[1]));
-    __builtin_amdgcn_sched_barrier(0);
-    const float xpub = xnext;
-    xnext = load_x(t + 3 < Tn ? t + 3 : Tn - 1);
-    auto req = [&](int k, KOps& o) __attribute__((always_inline)) {
-      const unsigned off = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
-      o.hi = *reinterpret_cast<const u32x4*>(hp + off);
-      o.lo = *reinterpret_cast<const u32x4*>(hp + PLH2 + off);
-    };
-    KOps o0, o1;
-    f32x4 ah[2][2] = {{z4, z4}, {z4, z4}}, al[2][2] = {{z4, z4}, {z4, z4}};     // [set][tile]: U.h scaled by 2^k
-    req(0, o0);
-    req(1, o1);
-    if (t > 0) store_step(t - 1, aux_prev);          // h_{t-1} (+ its pre-activation): issued during the LDS round trip
-    if (t + 2 < Tn) publish_x(cur, xpub);            // frame t+2 (buffer `cur` held frame t, last read before the barrier)
-    __builtin_amdgcn_sched_barrier(0);
-    SPLIT_STAMP(1)
-    static_for<KS2>([&](auto k_tag) __attribute__((always_inline)) {
-      constexpr int k = decltype(k_tag)::value;
-      constexpr int st = k & 1;
-      {
-        const KOps& o = st ? o1 : o0;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {                                                 // .cu:368, scaled by 2^k
-          al[st][mt] = mfma_f16(Uh[mt][k].lo, o.hi, al[st][mt]);
-          al[st][mt] = mfma_f16(Uh[mt][k].hi, o.lo, al[st][mt]);
-          ah[st][mt] = mfma_f16(Uh[mt][k].hi, o.hi, ah[st][mt]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (k >= 1 && k + 1 < KS2) {
-        // K-step k-1 has retired once its accumulators can be read; its operand set is then free for K-step k+1
-        constexpr int pv = st ^ 1;
-        float touch = ah[pv][0][0] + ah[pv][1][0] + al[pv][0][0] + al[pv][1][0];
-        if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
-        // the set's registers stay allocated up to here (the compiler considers an operand dead once its MFMAs have
-        // ISSUED and would hand its registers to the next request at once)
-        if constexpr (pv) asm volatile("" :: "v"(o1.hi), "v"(o1.lo)); else asm volatile("" :: "v"(o0.hi), "v"(o0.lo));
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (pv) req(k + 1, o1); else req(k + 1, o0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    });
-    SPLIT_STAMP(2)
-    // ---- epilogue: .cu:55-58 (reading every accumulator: the step's MFMAs have retired) ------------------------
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const f32x4 pre = wx[mt] + ((ah[0][mt] + ah[1][mt]) + (al[0][mt] + al[1][mt])) * u_unscale;
-      const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 16 * mt]);
-      const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 16 * mt]);
-      f32x4 zq, cq;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z = gate_act<GATE>(pre[r] + bzq[r]);
-        const float c = ftanh(pre[r] + bhq[r]);
-        hown[mt][r] = (sz * (1.0f - z) + sn) * c + hown[mt][r] * z;
-        zq[r] = z; cq[r] = c;
-      }
-      if (AUX == 1 && valid) {                       // reference operator outputs: stored at once
-        const size_t o = (size_t)t * B * H2 + lane_hs + 16 * mt;
-        st4(zs + o, zq); st4(cs + o, cq);
-      }
-      aux_prev[mt] = pre;
-    }
-    asm volatile("" :: "v"(o0.hi), "v"(o0.lo), "v"(o1.hi), "v"(o1.lo));      // (both sets: allocated until the reads above)
-    SPLIT_STAMP(3)
-    publish_h(nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < Tn) wx_issue(nxt);                   // W.x_{t+1}: frame t+1's planes were published a step ago
-    SPLIT_STAMP(4)
-    lds_barrier();
-    SPLIT_STAMP(5)
-  }
-#ifdef FASTGRNN_DIAG_STAMPS
-  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
-#endif
-  store_step(Tn - 1, aux_prev);
-  } else {
   __syncthreads();                                   // sbias staged; bf16 path: every wave's plane-2 fragments written
   publish_h(0);
   publish_x(0, load_x(0));
@@ -331,12 +206,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
   __syncthreads();
 
   f32x4 aux_prev[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#ifdef FASTGRNN_DIAG_STAMPS
-  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
-#endif
   for (int t = 0; t < Tn; ++t) {
-    SPLIT_STAMP(0)
     const int cur = H16 ? (t & 1) : 0, nxt = H16 ? (cur ^ 1) : 0;
     const float xpub = xnext;
     xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
@@ -375,7 +245,6 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    SPLIT_STAMP(1)
 #pragma unroll
     for (int k0 = 0; k0 < KS2; k0 += KB) {
       Frag2h hH[KB];
@@ -417,7 +286,6 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
       __builtin_amdgcn_sched_barrier(0);
     }
-    SPLIT_STAMP(2)
     // ---- epilogue: .cu:55-58 -----------------------------------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -438,21 +306,14 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       }
       aux_prev[mt] = pre;
     }
-    SPLIT_STAMP(3)
     if (!H16) {                                      // single-buffered planes: everyone has read h_{t-1}, x_t by now
       lds_barrier();
       publish_x(0, xpub);
     }
     publish_h(nxt);
-    SPLIT_STAMP(4)
     lds_barrier();
-    SPLIT_STAMP(5)
   }
-#ifdef FASTGRNN_DIAG_STAMPS
-  if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
-#endif
   store_step(Tn - 1, aux_prev);
-  }
   {                                                  // the weight fragments stay allocated through the last step
     float probe = hown[0][0];
 #pragma unroll
@@ -560,6 +421,8 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   auto ldg = [](const float* base, unsigned off) __attribute__((always_inline)) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
   };
+  const unsigned dp_step = valid ? (unsigned)B * H2 * 4u : 0u;
+  const unsigned dp_off = valid ? lane_v : (((unsigned)Tn * (unsigned)B + i) * H2 + n0) * 4u;
   auto stg = [](float* base, unsigned off, f32x4 v) __attribute__((always_inline)) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + off) = v;
   };
@@ -621,10 +484,13 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       }
     }
     kahan_add(pn, pn_c, sn8); kahan_add(pz, pz_c, sz8);
-    if (valid) {                                     // d_pre_t for the weight-gradient / d_x GEMMs
-      float* o = dpre_ws + (size_t)t * B * H2;
+    {
+      // d_pre_t for the weight-gradient / d_x GEMMs.  Every lane stores, without a branch: lanes beyond a ragged
+      // batch write to 16 sink rows behind the T*B rows (step stride 0) -- no conditional code around memory
+      // instructions in the steady state of a scan (the wide-layer backward's masked store block)
+      char* o = reinterpret_cast<char*>(dpre_ws) + (size_t)t * dp_step + dp_off;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) stg(o, lane_v + 64u * mt, dpv[mt]);
+      for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(o + 64 * mt) = dpv[mt];
     }
     // ---- the slice's power of two: largest |d_pre| of utterance i over this wave's 32 units into [2^11, 2^12) ---
     amax = fmaxf(amax, __shfl_xor(amax, 16));
@@ -786,7 +652,7 @@ H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   H256BwdWs L; size_t o = 0;
   L.part = o; o += align256(nwg * SLAB2 * 4);
-  L.dpre = o; o += align256(TB * H2 * 4);
+  L.dpre = o; o += align256((TB + 16) * H2 * 4);     // + 16 sink rows for the lanes beyond a ragged batch
   const size_t tn_u = tn_gemm_big_ws(TB, H2, H2), tn_w = tn_gemm_big_ws(TB, H2, F2);
   L.tn = o; o += tn_u > tn_w ? tn_u : tn_w;
   L.total = o;
@@ -847,8 +713,9 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
   // dU = d_pre^T . H_prev (rows of t = 0 are h0, the rest hs[t-1]);  dW = d_pre^T . X   (.cu:539-540 over all steps)
   tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
   tn_gemm_big_run(TB, H2, F2, dpre, H2, (const float*)x, (const float*)x, (size_t)0, F2, tn, (float*)g.d_w, F2, s);
-  // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N])
-  rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, g.d_x, false, false, s);
+  // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N]); skipped when the caller does not want the input's gradient
+  // (g.d_x == NULL: the first layer of a model, whose input is data)
+  if (g.d_x) rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, g.d_x, false, false, s);
 }
 
 }  // namespace
@@ -862,6 +729,8 @@ bool h256_shape(const fastgrnn_desc& d) {
 bool h256_supported(const fastgrnn_desc& d, int direction) {
   if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
   if (d.flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) return false;
+  // 32-bit byte offsets inside the d_pre workspace, its 16 sink rows included
+  if (((double)d.T * d.B + 16.0) * H2 * 4.0 >= 4294967296.0) return false;
   if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   return d.gate_nl <= FASTGRNN_NL_TANH || direction == 0 || preact;

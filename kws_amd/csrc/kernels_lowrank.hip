@@ -321,7 +321,16 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
   // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
   // of a 64-bit pointer pair each (the host rejects B*H*4 >= 2^31 for this path).
-  const unsigned lane_h = (unsigned)bc * rsB * H + n0, lane_hs = (unsigned)b * H + n0, lane_0 = (unsigned)bc * H + n0;
+  const unsigned lane_h = (unsigned)bc * rsB * H + n0, lane_0 = (unsigned)bc * H + n0;
+  // stores: rows of the two workspace tensors advance by B per step for the lanes of the batch and not at all for
+  // the others, whose rows are the 16 sink rows behind row T*B; d_x likewise, its sink behind d_m's
+  const unsigned sk_step = valid ? (unsigned)B : 0u;
+  const unsigned sk_row = valid ? (unsigned)b : (unsigned)Tn * (unsigned)B + i;
+  const unsigned dp_off = (sk_row * H + n0) * 4u, dm_off = (sk_row * 32 + 8 * g) * 4u;
+  constexpr unsigned XSZ = BF ? 2u : 4u;
+  char* const dx_base = valid ? reinterpret_cast<char*>(d_x) + ((size_t)b * xsB * F + (wv & 1) * 16 + 4 * g) * XSZ
+                              : reinterpret_cast<char*>(dm_ws) + (((size_t)Tn * B + 16) * 32 + i * 32 + (wv & 1) * 16 + 4 * g) * 4u;
+  const unsigned dx_step = valid ? (unsigned)xsT * F * XSZ : 0u;
   auto ld4s = [&](const float* base, unsigned e) __attribute__((always_inline)) -> f32x4 {   // 4 sequence elements
     if (BF) {
       const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e);
@@ -388,10 +397,12 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     __builtin_amdgcn_sched_barrier(0);
     if (t > 0) load_ew(t - 1, e);
     __builtin_amdgcn_sched_barrier(0);
-    if (valid) {
-      float* o = dpre_ws + (size_t)t * B * H + lane_hs;
+    {
+      // every lane stores, without a branch: lanes beyond a ragged batch write to sink rows behind the T*B rows
+      // (step stride 0) -- no exec-masked block around memory instructions in the steady state
+      char* o = reinterpret_cast<char*>(dpre_ws) + (size_t)t * sk_step * (H * 4u) + dp_off;
 #pragma unroll
-      for (int mt = 0; mt < NT; ++mt) st4(o + 4 * mt, dpv[mt]);
+      for (int mt = 0; mt < NT; ++mt) *reinterpret_cast<f32x4*>(o + 16 * mt) = dpv[mt];
     }
     // ---- rank-space partial over own units: B operand = this lane's two fragments of d_pre ----
     Frag3 dfr[KU];
@@ -414,9 +425,9 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
       mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
     }
-    if (wv == 0 && valid) {                          // [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
-      float* mo = dm_ws + (size_t)t * B * 32 + ((unsigned)b * 32 + 8 * g);
-      st4(mo, mlo); st4(mo + 4, mhi);
+    if (wv == 0) {                                   // (wave-uniform) [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
+      char* mo = reinterpret_cast<char*>(dm_ws) + (size_t)t * sk_step * (32 * 4u) + dm_off;
+      *reinterpret_cast<f32x4*>(mo) = mlo; *reinterpret_cast<f32x4*>(mo + 16) = mhi;
     }
     const Frag3 mB = split3(mlo, mhi);
     // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
@@ -427,13 +438,10 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       f32x4 dxv = f32x4{0.f, 0.f, 0.f, 0.f}, dxl = dxv;
       mfma6_hl(W1Tf, mB, dxv, dxl);
       dxv += dxl;
-      if (valid) {
-        const size_t o = (size_t)t * xsT * F + ((unsigned)b * xsB * F + wv * 16 + 4 * g);
-        if (BF) st4_bf16(reinterpret_cast<unsigned short*>(d_x) + o, dxv); else st4(d_x + o, dxv);
+      {                                              // lanes beyond a ragged batch: the sink behind d_m (dx_base)
+        char* o = dx_base + (size_t)t * dx_step;
+        if (BF) st4_bf16(o, dxv); else *reinterpret_cast<f32x4*>(o) = dxv;
       }
-      // these are the step's youngest MFMAs: an unconditional read of their result (the store above is skipped
-      // by lanes beyond a ragged batch) before the next step's requests may reuse their operand registers
-      if (RAGGED && dxv[0] == 1.2345678e38f) red[1] = 1.f;
     }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
@@ -763,8 +771,8 @@ struct LowrankBwdWs { size_t dpre, dm, part, splitk, xt, dxt, total; };
 LowrankBwdWs lowrank_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   LowrankBwdWs L; size_t o = 0;
-  L.dpre = o; o += align256(TB * 256 * 4);
-  L.dm = o; o += align256(TB * 32 * 4);
+  L.dpre = o; o += align256((TB + 16) * 256 * 4);    // + 16 sink rows (lanes beyond a ragged batch)
+  L.dm = o; o += align256((TB + 32) * 32 * 4);       // + 16 sink rows, + 16 more as the sink of d_x
   L.part = o; o += align256(nwg * SLAB_LR * 4);
   L.splitk = o; o += align256((size_t)tn_nwg(TB) * 256 * 32 * 4);   // partial C of the largest product, per workgroup
   L.xt = L.dxt = o;
@@ -892,7 +900,7 @@ bool lowrank_shape(const fastgrnn_desc& d) {
 bool lowrank_supported(const fastgrnn_desc& d, int direction) {
   if (d.gate_nl > FASTGRNN_NL_TANH || d.update_nl != FASTGRNN_NL_TANH) return false;
   // the backward scan addresses a step's rows with 32-bit offsets: whole sequence tensors below 2^32 bytes
-  if ((double)d.T * d.B * 256 * 4.0 >= 4294967296.0) return false;
+  if (((double)d.T * d.B + 16.0) * 256 * 4.0 >= 4294967296.0) return false;   // (the workspace tensors carry 16 sink rows)
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (direction == 0) {
     if ((d.flags & FASTGRNN_FLAG_HS_LAST) && preact) return false;

@@ -1032,7 +1032,7 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
     tn_gemm_big_run(TB, 128, d.F, dpre, 128, (const float*)x, (const float*)x, (size_t)0, d.F,
                     reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.tn), (float*)g.d_w, d.F, s);
     // d_x[T*B,F] = d_pre . W   (.cu:538 for every step at once; W is [H,F] = [K,N])
-    rows_gemm(TB, d.F, 128, true, dpre, (const float*)p.w, g.d_x, false, false, s);
+    if (g.d_x) rows_gemm(TB, d.F, 128, true, dpre, (const float*)p.w, g.d_x, false, false, s);   // (NULL: not wanted)
   }
 }
 
@@ -1171,6 +1171,8 @@ size_t split_forward_ws(const fastgrnn_desc& d) {
 }
 
 bool split_forward_ws_optional(const fastgrnn_desc& d) { return dense_wide_shape(d); }
+// shapes whose d_x is a GEMM of its own behind the scan: the caller may pass d_x = NULL to skip it
+bool split_dx_optional(const fastgrnn_desc& d) { return dense_wide_shape(d) || h256_shape(d); }
 
 size_t split_backward_ws(const fastgrnn_desc& d) {
   if (h256_shape(d)) return h256_backward_ws(d);

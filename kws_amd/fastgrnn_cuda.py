@@ -226,7 +226,7 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
 
 
 def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w1, w2, u1, u2, gate_nl,
-                   unrolled, update_nl, flags, bias_gate=None, bias_update=None):
+                   unrolled, update_nl, flags, bias_gate=None, bias_update=None, need_dx=True):
     lib = _lib.load()
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
     if preact:
@@ -273,7 +273,11 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
     with torch.cuda.device(dev):
         mk = lambda *s: torch.empty(s, dtype=pdt, device=dev)
         none = lambda: torch.empty(0)
-        d_input = torch.empty(tuple(input.shape), dtype=dt, device=dev)
+        # the input's gradient is a GEMM of its own on these shapes (fastgrnn_hip.h, fastgrnn_grads.d_x): skipped
+        # when autograd does not ask for it (a model's first layer)
+        skip_dx = (not need_dx and plan[2] == 2 and not w_lr and not u_lr and
+                   (desc.H == 256 or (desc.H == 128 and desc.F > 32)))
+        d_input = torch.empty(0) if skip_dx else torch.empty(tuple(input.shape), dtype=dt, device=dev)
         d_old_h = mk(B, H)
         # The parameter gradients are views of ONE flat buffer, laid out in the order the modules register
         # their parameters (W | W1,W2 ; U | U1,U2 ; bias_gate ; bias_update ; zeta ; nu).  autograd adopts
@@ -336,11 +340,12 @@ def forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_n
 
 
 def backward_unroll(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h, w1, w2, u1, u2,
-                    z_non_linearity, *, update_non_linearity=2, flags=0, bias_gate=None, bias_update=None):
+                    z_non_linearity, *, update_non_linearity=2, flags=0, bias_gate=None, bias_update=None,
+                    need_dx=True):
     """fastgrnn_cuda.cpp:182-232 -> 12 tensors (.cu:556).  With ``flags & FLAG_SAVE_PREACT``
     (extension, kernel path 2) ``z`` is the pre-activation tensor returned by
     ``forward_unroll(..., flags=FLAG_SAVE_PREACT)``, ``h_prime`` is ignored and the two bias
     tensors must be given."""
     return _backward_impl(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h,
                           w1, w2, u1, u2, z_non_linearity, True, update_non_linearity, flags,
-                          bias_gate=bias_gate, bias_update=bias_update)
+                          bias_gate=bias_gate, bias_update=bias_update, need_dx=need_dx)

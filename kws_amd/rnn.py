@@ -137,14 +137,15 @@ class FastGRNNUnrollFunction(Function):
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     pre_s, aux2, old_h, w1, w2, u1, u2, ctx.gate_non_linearity,
                                                     flags=flags, bias_gate=bias_gate,
-                                                    bias_update=bias_update)
+                                                    bias_update=bias_update, need_dx=ctx.needs_input_grad[0])
         else:
             (input, hidden_states, zeta, nu, w, u, z_s, h_prime_s, old_h, w1, w2, u1, u2) = ctx.saved_tensors
             outputs = fastgrnn_cuda.backward_unroll(grad_h.contiguous(), input, hidden_states, zeta, nu, w, u,
                                                     z_s, h_prime_s, old_h, w1, w2, u1, u2,
-                                                    ctx.gate_non_linearity, flags=flags)
+                                                    ctx.gate_non_linearity, flags=flags,
+                                                    need_dx=ctx.needs_input_grad[0])
         if ctx.flags & _lib.FLAG_X_BFT:                 # d_input was produced as [B,F,T]: hand back the [T,B,F] view
-            outputs = [outputs[0].permute(2, 0, 1)] + list(outputs[1:])
+            outputs = [outputs[0].permute(2, 0, 1) if outputs[0].numel() else outputs[0]] + list(outputs[1:])
         return _as_autograd_grads(outputs, ctx.needs_input_grad) + (None, None)
 
 

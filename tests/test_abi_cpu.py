@@ -91,6 +91,14 @@ def test_argument_validation_without_launch(lib):
     g = _lib.Grads()
     st = lib.fastgrnn_hip_backward_unroll(C.byref(dg), C.byref(pf), one, one, one, one, one, one, C.byref(g), null, 0, null)
     assert st == 1
+    # d_x alone missing: an error on the shapes whose scan produces it, accepted (-> the workspace check, 5) where it
+    # is a GEMM of its own behind the scan (dense H=256, dense H=128 with F > 32; kernel path 2)
+    gx = _lib.Grads(*([null] + [one] * 11))
+    d128 = _desc(B=4, T=3, flags=_lib.FLAG_SAVE_PREACT)
+    assert lib.fastgrnn_hip_backward_unroll(C.byref(d128), C.byref(pf), one, one, one, one, one, one, C.byref(gx), null, 0, null) == 1
+    for kw in (dict(H=256), dict(F=256)):
+        dd = _desc(B=4, T=3, flags=_lib.FLAG_SAVE_PREACT, **kw)
+        assert lib.fastgrnn_hip_backward_unroll(C.byref(dd), C.byref(pf), one, one, one, one, one, one, C.byref(gx), null, 0, null) == 5
 
 
 def test_last_state_flags_are_refused_where_no_kernel_implements_them(lib):

@@ -270,3 +270,36 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
         m.init_hidden()
         scores = m(_t(x))
     assert (np.abs(scores.cpu().numpy() - scores_o) / np.maximum(1.0, np.abs(scores_o))).max() <= 1e-5
+
+
+@pytest.mark.parametrize("F,H", [(32, 256), (256, 128), (64, 128)])
+def test_input_gradient_is_optional_where_it_is_a_gemm_of_its_own(F, H):
+    """fastgrnn_grads.d_x may be NULL on the H=256 and wide-input shapes (a model's first layer: its input is data):
+    the d_x GEMM is skipped, every other gradient is bit-identical; elsewhere a NULL d_x stays an error."""
+    T, B = 9, 37
+    rng = np.random.default_rng(3)
+    p = O.make_params(F, H, dtype=np.float32, seed=37, randomize_scalars=True)
+    P = _P(p)
+    e = torch.empty(0)
+    x = _t(rng.standard_normal((T, B, F)).astype(np.float32))
+    h0 = _t((0.5 * rng.standard_normal((B, H))).astype(np.float32))
+    G = _t(rng.standard_normal((T, B, H)).astype(np.float32))
+    fl = _lib.FLAG_SAVE_PREACT
+    outs = fastgrnn_cuda.forward_unroll(x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0,
+                                        e, e, e, e, flags=fl)
+    run = lambda need: fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1], h0,
+                                                     e, e, e, e, 0, flags=fl, bias_gate=P["bias_gate"],
+                                                     bias_update=P["bias_update"], need_dx=need)
+    full, lean = run(True), run(False)
+    assert full[0].shape == x.shape and lean[0].numel() == 0
+    for a, b in zip(full[1:8], lean[1:8]):
+        assert torch.equal(a, b)
+    # through autograd: an input that does not require grad
+    m = FastGRNNCUDA(F, H, device=DEV)
+    m(x).square().mean().backward()
+    g1 = [q.grad.clone() for q in m.parameters()]
+    for q in m.parameters():
+        q.grad = None
+    xr = x.clone().requires_grad_(True)
+    m(xr).square().mean().backward()
+    assert xr.grad is not None and all(torch.equal(a, q.grad) for a, q in zip(g1, m.parameters()))
