@@ -196,8 +196,8 @@ void launch_rows_gemm(size_t R, const void* A, const float* W, void* C, bool bf_
 // Workgroup = 8 waves = one chunk of rows x one 128-column block of A.  Stages of 32 rows (one MFMA
 // K-step): global fp32 -> three exact bf16 planes in LDS in natural [row][column] order (double-buffered, the
 // next stage's loads in flight under the MFMAs) -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs
-// into register accumulators.  Wave w owns m-tiles 2(w&3), 2(w&3)+1 of the block and n-tiles (w>>2)*NT/2 ...:
-// two A fragments for the stage, B fragments in batches of four.  Each workgroup leaves its partial C in the
+// into register accumulators.  A wave owns MA m-tiles x NT/MA n-tiles (4 x NT/4 for NT >= 8, else 2 x NT/2): its A
+// fragments are read once per stage, its B fragments in batches.  Each workgroup leaves its partial C in the
 // workspace; tn_big_reduce sums them in a fixed order (deterministic, no atomics).
 // Rows of B below shiftB come from B0 (h0: H_prev of step 0), the rest from B1 shifted down by shiftB rows.
 constexpr int TNB_STAGE = 32;
@@ -206,17 +206,21 @@ template <int NT>
 __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B0, const float* __restrict__ B1,
                                                    size_t shiftB, int ldb, float* __restrict__ part) {
-  constexpr int MB = 128, N = 16 * NT, NH = NT / 2, NBATCH = NH < 4 ? NH : 4;
+  // wave tiling of the 8 x NT output tiles: MA m-tiles x NH n-tiles per wave.  4 x NT/4 where NT allows it (per stage
+  // 4 A + NT/4 B fragment sets per wave instead of 2 + NT/2: a fifth fewer LDS reads at NT = 16, the kernel's
+  // co-bottleneck), else 2 x NT/2
+  constexpr int MB = 128, N = 16 * NT, MA = NT >= 8 ? 4 : 2, NWM = 8 / MA, NH = NT / MA;
+  constexpr int NBATCH = MA == 4 ? (NH < 2 ? NH : 2) : (NH < 4 ? NH : 4);
   constexpr int ROWA = MB * 2 + 32, ROWB = N * 2 + 32;
   constexpr int VA = TNB_STAGE * MB / 4 / 512, VB = (TNB_STAGE * N / 4 + 511) / 512;   // float4 per thread per stage
-  static_assert(NT % 2 == 0 && NH % NBATCH == 0 && VA >= 1, "shape");
+  static_assert(NT % MA == 0 && NH % NBATCH == 0 && VA >= 1, "shape");
   __shared__ __attribute__((aligned(16))) unsigned char la[2][3][TNB_STAGE * ROWA];
   __shared__ __attribute__((aligned(16))) unsigned char lb[2][3][TNB_STAGE * ROWB];
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
-  const int mq = wv & 3, nh = wv >> 2;
+  const int mq = wv % NWM, nh = wv / NWM;
   // consecutive workgroups take the column blocks of ONE row chunk: they run at the same time and read the same rows
   // of B, so the second read comes from the Infinity Cache instead of HBM
   const int mblk = blockIdx.x % nblk;              // 128-column block of A
@@ -267,16 +271,16 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     }
   };
 
-  f32x4 acc[2][NH];
+  f32x4 acc[MA][NH];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int c = 0; c < NH; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (s_begin < s_end) {
     const unsigned la0 = (unsigned)(size_t)&la[0][0][0], lb0 = (unsigned)(size_t)&lb[0][0][0];
     // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
-    const unsigned trA = la0 + (8 * g + q) * ROWA + (mq * 32 + 4 * pp) * 2;
+    const unsigned trA = la0 + (8 * g + q) * ROWA + (mq * MA * 16 + 4 * pp) * 2;
     const unsigned trB = lb0 + (8 * g + q) * ROWB + (nh * NH * 16 + 4 * pp) * 2;
     Stage S0, S1;
     load_stage(s_begin, S0);
@@ -288,9 +292,9 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     // then -- behind the barrier, i.e. behind every MFMA of the stage -- the request for stage st + 3 into Snext
     auto stage = [&](size_t st, int buf, Stage& Snext) __attribute__((always_inline)) {
       const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * 3 * TNB_STAGE * ROWB;
-      Frag3 Af[2];
+      Frag3 Af[MA];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < MA; ++a)
 #pragma unroll
         for (int p = 0; p < 3; ++p) Af[a].p[p] = tr_frag(trA + oa + p * (TNB_STAGE * ROWA) + a * 32, ROWA);
 #pragma unroll
@@ -304,11 +308,13 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
 #pragma unroll
         for (int c = 0; c < NBATCH; ++c)
 #pragma unroll
-          for (int a = 0; a < 2; ++a) acc[a][c0 + c] = mfma6(Af[a], Bf[c], acc[a][c0 + c]);
+          for (int a = 0; a < MA; ++a) acc[a][c0 + c] = mfma6(Af[a], Bf[c], acc[a][c0 + c]);
         __builtin_amdgcn_sched_barrier(0);
         float touch = 0.f;                         // all of the batch's MFMAs have retired before Bf / Af are reloaded
 #pragma unroll
-        for (int c = 0; c < NBATCH; ++c) touch += acc[0][c0 + c][0] + acc[1][c0 + c][0];
+        for (int c = 0; c < NBATCH; ++c)
+#pragma unroll
+          for (int a = 0; a < MA; ++a) touch += acc[a][c0 + c][0];
         if (touch == 1.2345678e38f) part[0] = 1.f;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -329,12 +335,12 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   // D row 4g + r of tile (mt, nt) is m = 16 mt + 4g + r, column n = 16 nt + (l & 15)
   float* pc = part + ((size_t)chunk * nblk + mblk) * MB * N;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int c = 0; c < NH; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pc[(size_t)(mq * 32 + a * 16 + 4 * g + r) * N + (nh * NH + c) * 16 + (l & 15)] = acc[a][c][r];
+        pc[(size_t)((mq * MA + a) * 16 + 4 * g + r) * N + (nh * NH + c) * 16 + (l & 15)] = acc[a][c][r];
 }
 
 // C[(mblk*128 + m) * ldc + n] = sum over row chunks of part[chunk][mblk][m][n], fixed order

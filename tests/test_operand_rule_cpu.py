@@ -22,7 +22,7 @@ SCAN = os.path.join(ROOT, "tools", "war_scan.py")
 
 
 # (source, minimum number of kernel instantiations scanned)
-SOURCES = [("kernels_split.hip", 100), ("kernels_mfma.hip", 50), ("kernels_gemm.hip", 4), ("kernels_h256.hip", 50),
+SOURCES = [("kernels_split.hip", 100), ("kernels_mfma.hip", 40), ("kernels_gemm.hip", 4), ("kernels_h256.hip", 50),
            ("kernels_lowrank.hip", 50)]
 
 
