@@ -733,18 +733,25 @@ __global__ __launch_bounds__(256) void bft_transpose(int B, int T, const E* __re
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int tc = 0; tc < T; tc += 64) {
     __syncthreads();
+    // all (predicated) loads first, then unconditional LDS writes: no LDS write sits in front of a branch with memory
+    // instructions behind it (tools/lds_branch_vmem_scan.py)
+    E v[8];
     if (TO_TBF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int f = (tid >> 6) + 4 * k, tt = tid & 63;
-        if (tc + tt < T) tile[f][tt] = src[((size_t)b * F + f) * T + tc + tt];
+        v[k] = (tc + tt < T) ? src[((size_t)b * F + f) * T + tc + tt] : E(0);
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[(tid >> 6) + 4 * k][tid & 63] = v[k];
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int tt = (tid >> 5) + 8 * k, f = tid & 31;
-        if (tc + tt < T) tile[f][tt] = src[((size_t)(tc + tt) * B + b) * F + f];
+        v[k] = (tc + tt < T) ? src[((size_t)(tc + tt) * B + b) * F + f] : E(0);
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[tid & 31][(tid >> 5) + 8 * k] = v[k];
     }
     __syncthreads();
     if (TO_TBF) {

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Sites of the pattern  LDS instruction ... conditional branch ... vector-memory instruction  with no
+`s_waitcnt lgkmcnt(0)` (or barrier) between the LDS instruction and the branch, inside loops of gfx950 assembly.
+
+    python tools/lds_branch_vmem_scan.py file.s [window=12]
+
+Background: the ragged wide-layer backward had exactly this in its scan loop -- three ds_write2st64,
+`s_and_saveexec` + `s_cbranch_execz`, address arithmetic, `global_store` -- and returned wrong results in some
+processes.  Any ONE of these removed the failures in interleaved A/B runs (0 of 10 processes against 6 of 10): idle
+cycles in front of the block; idle cycles behind the store; `s_waitcnt lgkmcnt(0)` in front of the block; the address
+arithmetic hoisted out of the block; the block moved in front of the LDS writes.  gfx10 has a documented hazard of this
+shape (LLVM's LdsBranchVmemWARHazard); nothing is documented for gfx9.  The shipped scans therefore keep conditional
+branches away from memory instructions in their loops; this scanner lists what is left.  Exit status 0 always
+(informational); prints one line per kernel with a finding.
+"""
+import re
+import sys
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+path = args[0]
+W = int(args[1]) if len(args) > 1 else 12
+VMEM = ("global_", "buffer_", "flat_", "scratch_")
+
+
+def kernels(path):
+    name, body = None, []
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            yield name, body
+            name = None
+            continue
+        t = line.split(";")[0].strip()
+        if t and (not t.startswith(".") or re.match(r"^\.L\w+:", t)):
+            body.append(t)
+
+
+REG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+)\b)")
+
+
+def vregs(tok):
+    out = set()
+    for m in REG.finditer(tok):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+NARROW = "--narrow" in sys.argv      # only: LDS WRITE whose data registers a VALU instruction behind the branch overwrites
+total = 0
+for name, body in kernels(path):
+    labels = {}
+    ins = []
+    for t in body:
+        m = re.match(r"^(\.L\w+):", t)
+        if m:
+            labels[m.group(1)] = len(ins)
+        else:
+            ins.append(t)
+    # loop ranges: a branch back to an earlier label
+    loops = []
+    for j, t in enumerate(ins):
+        m = re.match(r"s_c?branch\w*\s+(\.L\w+)", t)
+        if m and m.group(1) in labels and labels[m.group(1)] <= j:
+            loops.append((labels[m.group(1)], j))
+    hits = []
+    for j, t in enumerate(ins):
+        if not t.startswith("s_cbranch"):
+            continue
+        if not any(a <= j <= b for a, b in loops):
+            continue
+        lds = None
+        data = set()
+        for k in range(j - 1, max(-1, j - 1 - W), -1):
+            u = ins[k]
+            if u.startswith("s_barrier") or (u.startswith("s_waitcnt") and "lgkmcnt(0)" in u):
+                break
+            if u.startswith("ds_") and (not NARROW or u.startswith(("ds_write", "ds_store"))):
+                if lds is None:
+                    lds = u
+                ops = u.split(None, 1)[1].split(",") if " " in u else []
+                for o in ops[1:]:
+                    data |= vregs(o)
+                if not NARROW:
+                    break
+        if lds is None:
+            continue
+        if NARROW:
+            clobber = None
+            for k in range(j + 1, min(len(ins), j + 1 + W)):
+                u = ins[k]
+                if u.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_waitcnt")):
+                    break
+                if u.startswith("v_") and not u.startswith("v_cmp"):
+                    ops = u.split(None, 1)[1].split(",") if " " in u else []
+                    if ops and (vregs(ops[0]) & data):
+                        clobber = u
+                        break
+            if clobber is None:
+                continue
+        vm = None
+        for k in range(j + 1, min(len(ins), j + 1 + W)):
+            u = ins[k]
+            if u.startswith(VMEM):
+                vm = u
+                break
+            if u.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                break
+        if vm:
+            hits.append((lds.split()[0], t.split()[0], vm.split()[0]))
+    if hits:
+        total += len(hits)
+        short = re.sub(r"^_ZN8fastgrnn12_GLOBAL__N_1\d+", "", name)[:60]
+        print("%-62s %2d  e.g. %s -> %s -> %s" % (short, len(hits), *hits[0]))
+print("sites in loops:", total)
