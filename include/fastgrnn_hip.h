@@ -163,9 +163,13 @@ const char *fastgrnn_hip_status_string(int status);
  *   dense  H=256, F=32            (the reference's first layer) fp32, time-major, gates sigmoid / relu / tanh.
  *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are
  *                                 zero-extended to 16 inside the kernels): gates sigmoid / relu / tanh; all layout
- *                                 flags; backward under FASTGRNN_FLAG_SAVE_PREACT only.  Ranks above 16 and cells
- *                                 with only one of W, U factorised (rnn.py:783-798) run on the generic scan.
- * Under FASTGRNN_FLAG_SAVE_PREACT a factorised forward also writes, through c_s, the rank-space vector
+ *                                 flags; backward under FASTGRNN_FLAG_SAVE_PREACT only.
+ *   other factorised H=256, F=32 cells (a rank of 17..256, or only one of W, U factorised: rnn.py:783-798): the
+ *                                 factors are multiplied out per call, the dense H=256 kernels run, the dense
+ *                                 gradients are projected onto the factors (as the reference's CUDA operator does
+ *                                 for every low-rank cell, .cu:353-362,546-555); that shape's limits apply.
+ *                                 No rank-space vector is saved (c_s is ignored under FASTGRNN_FLAG_SAVE_PREACT).
+ * Under FASTGRNN_FLAG_SAVE_PREACT a factorised forward with both ranks in 1..16 also writes, through c_s, the rank-space vector
  * [U1.h_{t-1} | W1.x_t] as a time-major fp32 [T*B, 32] tensor (each half zero-extended to 16 columns) that the
  * backward takes back through c_s. */
 int fastgrnn_hip_kernel_path(const fastgrnn_desc *d, int direction);

@@ -111,6 +111,17 @@ int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void
 int lowrank_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                      const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
 
+// other factorised H = 256 / F = 32 cells (rank above 16, or only one of W, U factorised) on the dense H = 256 scans:
+// the factors are multiplied out per call and the dense gradients projected back (kernels_densify.hip)
+bool densified_shape(const fastgrnn_desc& d);
+bool densified_supported(const fastgrnn_desc& d, int direction);
+size_t densified_forward_ws(const fastgrnn_desc& d);
+size_t densified_backward_ws(const fastgrnn_desc& d);
+int densified_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
+                      void* cs, void* ws, hipStream_t s);
+int densified_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
+                       const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
+
 // classifier head on the last state: Linear + log_softmax + NLL, forward and backward (kernels_head.hip)
 bool head_supported(int B, int H, int C);
 size_t head_ws_bytes(int B, int H, int C);

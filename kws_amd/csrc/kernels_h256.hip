@@ -502,7 +502,10 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     SPLIT_STAMP(1)
     lds_barrier();                                   // every wave has finished reading the planes of step t+1
     SPLIT_STAMP(2)
-    if (g == 0) sinv[i][wv] = ldexpf(u_unscale, ex - 12);
+    // (the slice's own factor only: the factor of U^T belongs to the CONSUMER's rows and is applied in req().  Round 2
+    // shipped this line with the producer's u_unscale folded in -- right only while every wave's block of U^T has its
+    // maximum in the same binade, which random 0.1-scale matrices happen to satisfy and a product U2.U1 does not)
+    if (g == 0) sinv[i][wv] = ldexpf(1.0f, ex - 12);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       uint2 hi, lo;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       o.dB.lo = *reinterpret_cast<const u32x4*>(dpl + PLH2 + off);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) o.Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
-      o.inv = sinv[i][k];
+      o.inv = sinv[i][k] * u_unscale;
     };
     auto issue = [&](int k, const KOps& o, f32x4* pr) __attribute__((always_inline)) {
 #pragma unroll

@@ -1140,6 +1140,7 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (h256_shape(d)) return h256_supported(d, direction);      // dense H = 256 / F = 32: kernels_h256.hip
   if (lowrank_shape(d)) return lowrank_supported(d, direction); // H = 256 / F = 32, ranks <= 16: kernels_lowrank.hip
+  if (densified_shape(d)) return densified_supported(d, direction);   // the other factorised H = 256 cells: kernels_densify.hip
   // dense H = 128 with a wider input (F = 64 / 128 / 256; the reference's second layer): recurrence-only scans +
   // batched GEMMs.  fp32 sequences, time- or batch-major, every gate, full or last-state outputs / gradients.
   if (dense_wide_shape(d)) {
@@ -1167,6 +1168,7 @@ size_t split_forward_ws(const fastgrnn_desc& d) {
   if (dense_wide_shape(d)) return align256((size_t)d.T * d.B * 128 * 4);
   if (h256_shape(d)) return h256_forward_ws(d);
   if (lowrank_shape(d)) return lowrank_forward_ws(d);
+  if (densified_shape(d)) return densified_forward_ws(d);
   return 0;
 }
 
@@ -1178,6 +1180,7 @@ size_t split_backward_ws(const fastgrnn_desc& d) {
   if (h256_shape(d)) return h256_backward_ws(d);
   if (dense_wide_shape(d)) return wide_bwd_layout(d).total;
   if (lowrank_shape(d)) return lowrank_backward_ws(d);
+  if (densified_shape(d)) return densified_backward_ws(d);
   return align256((size_t)((d.B + 15) / 16) * SLAB * 4);
 }
 
@@ -1186,6 +1189,7 @@ int split_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void*
                    hipStream_t s) {
   if (h256_shape(d)) return h256_backward(d, p, ghs, x, hs, zs, cs, h0, g, ws, s);
   if (lowrank_shape(d)) return lowrank_backward(d, p, ghs, x, hs, zs, cs, h0, g, ws, s);
+  if (densified_shape(d)) return densified_backward(d, p, ghs, x, hs, zs, cs, h0, g, ws, s);
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
@@ -1203,6 +1207,7 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
   if (d.dtype == FASTGRNN_BF16_IO && zs && !(d.flags & FASTGRNN_FLAG_SAVE_PREACT)) return FASTGRNN_ERR_UNSUPPORTED;
   if (h256_shape(d)) return h256_forward(d, p, x, h0, hs, zs, cs, ws, s);
   if (lowrank_shape(d)) return lowrank_forward(d, p, x, h0, hs, zs, cs, ws, s);
+  if (densified_shape(d)) return densified_forward(d, p, x, h0, hs, zs, cs, ws, s);
   void* pws = nullptr;
   if (dense_wide_shape(d)) {
     // P[T*B,H] = X . W^T, the one genuinely dense contraction of the layer (.cu:356 per step), into the buffer the

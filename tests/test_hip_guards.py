@@ -179,3 +179,50 @@ def test_sparsify_train_step_sparsify_with_support_through_the_operator(lowrank)
         m.sparsifyWithSupport()                             # ... and the remembered support removes them
         for w, old in zip(mats, m.oldmats):
             assert torch.equal(w == 0, (old == 0) | (w == 0)) and int(((old == 0) & (w != 0)).sum()) == 0
+
+
+@pytest.mark.parametrize("H,F,r", [(128, 32, None), (256, 32, None), (256, 32, 16), (128, 256, None)])
+def test_weights_whose_blocks_sit_in_different_binades(H, F, r):
+    """Several kernels scale a wave's block of a weight matrix by its own power of two (fp16 two-plane operands).  With
+    0.1 * randn matrices every block's maximum falls into the same binade and a mixed-up factor goes unnoticed (the
+    H=256 backward shipped one in round 2); here row AND column blocks of U (and W) differ by up to 2^5."""
+    T, B = 9, 37
+    rng = np.random.default_rng(13)
+    p = O.make_params(F, H, r, r, dtype=np.float32, seed=47, randomize_scalars=True)
+    nb = H // 16
+    rowf = np.repeat(np.array([(0.07, 1.9, 0.45, 1.0, 0.12, 2.6, 0.8, 0.3)[k % 8] for k in range(nb)], np.float32), 16)
+    colf = np.repeat(np.array([(1.3, 0.09, 0.6, 2.1, 0.25, 1.0, 0.5, 0.15)[k % 8] for k in range(nb)], np.float32), 16)
+    if r:
+        p["u2"] = (p["u2"] * rowf[:, None]).astype(np.float32); p["u1"] = (p["u1"] * colf[None, :]).astype(np.float32)
+        p["w2"] = (p["w2"] * rowf[::-1, None]).astype(np.float32)
+    else:
+        p["u"] = (0.6 * p["u"] * rowf[:, None] * colf[None, :]).astype(np.float32)
+        p["w"] = (p["w"] * rowf[::-1, None]).astype(np.float32)
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    fl = _lib.FLAG_SAVE_PREACT
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, r or 0, r or 0, 0, direction=1, flags=fl) == 2
+    outs = fastgrnn_cuda.forward_unroll(_t(x), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), 0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=fl)
+    gr = fastgrnn_cuda.backward_unroll(_t(G), _t(x), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
+                                       P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64))
+    assert (np.abs(outs[0].cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64, h0.astype(np.float64),
+                            diagnostics=True)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: v.cpu().numpy() for n, v in zip(names, gr) if v.numel()}
+    for k, v in g_o.items():
+        if k.startswith("_"):
+            continue
+        err = float(np.abs(g[k].reshape(v.shape) - v).max())
+        lim = 2e-5 * max(1.0, float(np.abs(v).max()))
+        if k in ("d_zeta", "d_nu"):
+            lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
+        assert err <= lim, (k, err, lim)

@@ -179,3 +179,54 @@ def test_module_lowrank_uses_the_layout_flags(kind):
     assert torch.equal(gx, x_ref.grad)
     for (n, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
         assert torch.equal(a.grad, b.grad), n
+
+
+@pytest.mark.parametrize("rw,ru,B,preact", [(32, 32, 37, True), (32, 32, 64, False), (16, None, 48, True), (None, 16, 33, True),
+                                            (64, 8, 16, True), (17, 16, 21, False)])
+def test_other_factorised_cells_run_on_the_dense_kernels(rw, ru, B, preact):
+    """Ranks above 16 and cells with only W or only U factorised (rnn.py:783-798): the factors are multiplied out per
+    call, the dense H=256 scans run, the dense gradients are projected onto the factors (what the reference's CUDA
+    operator does for every low-rank cell, .cu:353-362,546-555).  Against the fp64 oracle's FACTORISED evaluation."""
+    T = 11
+    rng = np.random.default_rng(5 + B)
+    p = O.make_params(F, H, rw, ru, dtype=np.float32, seed=29, randomize_scalars=True)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    fl = SAVE_PREACT if preact else 0
+    for direction in (0, 1):
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, 0, direction=direction, flags=fl) == 2
+    outs = fastgrnn_cuda.forward_unroll(_t(x), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), 0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=fl)
+    assert len(outs) == (2 if preact else 3)
+    gr = fastgrnn_cuda.backward_unroll(_t(G), _t(x), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
+                                       P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64))
+    assert (np.abs(outs[0].cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64, h0.astype(np.float64),
+                            diagnostics=True)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: v.cpu().numpy() for n, v in zip(names, gr) if v.numel()}
+    assert set(g) == {k for k in g_o if not k.startswith("_")}
+    for k, v in g_o.items():
+        if k.startswith("_"):
+            continue
+        err = float(np.abs(g[k].reshape(v.shape) - v).max())
+        lim = 2e-5 * max(1.0, float(np.abs(v).max()))
+        if k in ("d_zeta", "d_nu"):
+            lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
+        assert err <= lim, (k, err, lim)
+
+
+def test_module_with_rank_32_trains_on_the_matrix_pipe():
+    torch.manual_seed(5)
+    m = FastGRNNCUDA(F, H, wRank=32, uRank=32, device=DEV)
+    x = torch.randn(13, 40, F, device=DEV, requires_grad=True)
+    assert fastgrnn_cuda.kernel_path(13, 40, F, H, 32, 32, 0, direction=1, flags=SAVE_PREACT) == 2
+    m(x).square().mean().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters()) and x.grad is not None

@@ -303,3 +303,22 @@ def test_input_gradient_is_optional_where_it_is_a_gemm_of_its_own(F, H):
     xr = x.clone().requires_grad_(True)
     m(xr).square().mean().backward()
     assert xr.grad is not None and all(torch.equal(a, q.grad) for a, q in zip(g1, m.parameters()))
+
+
+@pytest.mark.parametrize("B,preact", [(37, True), (16, False)])
+def test_h256_with_column_blocks_of_U_in_different_binades(B, preact):
+    """The H=256 backward scales each wave's 32-column block of U by its own power of two: blocks whose largest
+    elements sit in different binades (any trained matrix; not the 0.1 * randn of the other tests) must come out
+    right too.  (The first build un-scaled with the PRODUCER wave's factor: wrong by powers of two here.)"""
+    T, F, H = 9, 32, 256
+    rng = np.random.default_rng(11)
+    p = O.make_params(F, H, dtype=np.float32, seed=43, randomize_scalars=True)
+    blk = np.repeat(np.array([1.0, 0.3, 2.2, 0.55, 0.13, 1.7, 0.9, 0.06], np.float32), 32)
+    p["u"] = (p["u"] * blk[None, :] * 0.5).astype(np.float32)        # columns k = 32w .. 32w+31 share a factor
+    x = rng.standard_normal((T, B, F)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
+    G = rng.standard_normal((T, B, H)).astype(np.float32)
+    outs, gr = _run(_t(x), _t(h0), _t(G), p, preact=preact)
+    hs_o, zs_o, cs_o, g_o = _oracle(x, G, p, h0)
+    assert np.abs(outs[0].cpu().numpy() - hs_o).max() <= 1e-5
+    _check(gr, g_o)
