@@ -12,7 +12,8 @@ SHAPES = [(99, 64, 256, 128, 1), (99, 50, 256, 128, 1), (23, 37, 256, 128, 0), (
           (9, 16, 32, 256, 0), (7, 33, 64, 128, 1), (5, 37, 32, 128, 1), (7, 33, 64, 128, 0), (8, 17, 64, 128, 1),
           (8, 33, 128, 128, 1), (7, 50, 256, 128, 0), (7, 32, 64, 128, 1), (7, 33, 32, 128, 1), (7, 33, 32, 128, 0),
           # low-rank (6th entry = rank) and H=256 ragged batches
-          (9, 33, 32, 256, 1, 16), (7, 50, 32, 256, 1, 8), (8, 17, 32, 256, 1, 16), (9, 33, 32, 256, 1), (8, 50, 32, 256, 0)]
+          (9, 33, 32, 256, 1, 16), (7, 50, 32, 256, 1, 8), (8, 17, 32, 256, 1, 16), (9, 33, 32, 256, 1), (8, 50, 32, 256, 0),
+          (7, 37, 32, 256, 1, 32)]                     # rank 32: factors multiplied out, dense H=256 kernels
 if os.environ.get("REPRO_BIG"):
     # full-size ragged batches (255 full workgroups + one with 10 utterances): what the last batch of an epoch looks like
     SHAPES += [(99, 4090, 32, 128, 1), (99, 4090, 32, 128, 0), (99, 4090, 256, 128, 1), (99, 4090, 32, 256, 1),
