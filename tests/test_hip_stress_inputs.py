@@ -1,6 +1,6 @@
 """GPU tests on input distributions the other tests do not visit.  Every parity test draws 0.1 * randn weights and
 N(0,1) data; one bug of round 2 (a per-block scale applied by the wrong wave) was invisible on exactly that
-distribution.  Here each kernel family sees: large and tiny weights, saturated gates, extreme zeta / nu, large frames,
+distribution.  Here each kernel family sees: large, tiny and sparsified weights (whole zero blocks), saturated gates, extreme zeta / nu, large frames,
 gradients of 1e-9 and 1e+5 (the H=256 backward rescales d_pre per slice), all-zero frames and all-zero gradients.
 Checked against the fp64 oracle RELATIVE to each output's own largest element (no absolute floor: a gradient of size
 1e-9 must be right to 2e-5 of 1e-9)."""
@@ -19,7 +19,7 @@ DEV = "cuda:0"
 FAMILIES = {"dense128": (32, 128, None), "wide256": (256, 128, None), "h256": (32, 256, None), "lowrank16": (32, 256, 16),
             "rank32": (32, 256, 32)}
 SCENARIOS = ["big_weights", "tiny_weights", "saturated", "zeta_nu_extreme", "big_frames", "tiny_grad", "huge_grad",
-             "zero_frames", "zero_grad", "two_steps"]
+             "zero_frames", "zero_grad", "two_steps", "sparse_weights"]
 
 
 def _t(a):
@@ -43,6 +43,16 @@ def test_unusual_inputs_against_the_oracle(family, scenario):
     elif scenario == "tiny_weights":
         for k in mats:
             p[k] = (p[k] * 1e-3).astype(np.float32)
+    elif scenario == "sparse_weights":
+        # what the trainer's IHT phase leaves (utils.py:53-63): most entries zero, and whole blocks of rows / columns
+        for k in mats:
+            m = p[k].copy()
+            m[rng.random(m.shape) < 0.9] = 0.0
+            if m.shape[0] >= 64:
+                m[32:64, :] = 0.0
+            if m.shape[1] >= 64:
+                m[:, 0:32] = 0.0
+            p[k] = m.astype(np.float32)
     elif scenario == "saturated":
         p["bias_gate"] = (p["bias_gate"] + 12.0 * np.sign(rng.standard_normal((1, H)))).astype(np.float32)
         p["bias_update"] = (p["bias_update"] * 6.0).astype(np.float32)
