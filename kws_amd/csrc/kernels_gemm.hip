@@ -221,6 +221,10 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
   const int mq = wv % NWM, nh = wv / NWM;
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   // consecutive workgroups take the column blocks of ONE row chunk: they run at the same time and read the same rows
   // of B, so the second read comes from the Infinity Cache instead of HBM
   const int mblk = blockIdx.x % nblk;              // 128-column block of A
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     // then -- behind the barrier, i.e. behind every MFMA of the stage -- the request for stage st + 3 into Snext
     auto stage = [&](size_t st, int buf, Stage& Snext) __attribute__((always_inline)) {
       const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * 3 * TNB_STAGE * ROWB;
+      SPLIT_STAMP(0)
       Frag3 Af[MA];
 #pragma unroll
       for (int a = 0; a < MA; ++a)
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
 #pragma unroll
           for (int p = 0; p < 3; ++p) Bf[c].p[p] = tr_frag(trB + ob + p * (TNB_STAGE * ROWB) + (c0 + c) * 32, ROWB);
         __builtin_amdgcn_sched_barrier(0);        // every fragment read of the batch is issued before its first MFMA
+        SPLIT_STAMP(1)                            // (diagnostic build: + the wait for the fragments)
 #pragma unroll
         for (int c = 0; c < NBATCH; ++c)
 #pragma unroll
@@ -317,11 +323,17 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
           for (int a = 0; a < MA; ++a) touch += acc[a][c0 + c][0];
         if (touch == 1.2345678e38f) part[0] = 1.f;
         __builtin_amdgcn_sched_barrier(0);
+        SPLIT_STAMP(2)
       }
       // (tried, same-run A/B: half of the waves publishing BEFORE their products, so that one wave's VALU split runs
       // beside its SIMD partner's MFMAs -- for either pairing of the waves 9-16 % slower: 281 -> 309 us at N = 256)
+      // (tried: the planes first and the requests in portions behind each batch's MFMAs, because cycle stamps --
+      // tools/diag_gemm.hip -- put 1 300-1 800 of a stage's 6 800 stamped cycles into issuing the six loads right
+      // behind the barrier: 276 -> 291 us in the same run)
       if (st + 1 < s_end) publish(buf ^ 1, Snext);
+      SPLIT_STAMP(3)
       lds_barrier();
+      SPLIT_STAMP(4)
       if (st + 3 < s_end) load_stage(st + 3, Snext);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -332,6 +344,9 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     }
     if (st < s_end) stage(st, 0, S0);
   }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
+#endif
   // D row 4g + r of tile (mt, nt) is m = 16 mt + 4g + r, column n = 16 nt + (l & 15)
   float* pc = part + ((size_t)chunk * nblk + mblk) * MB * N;
 #pragma unroll
