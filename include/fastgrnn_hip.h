@@ -164,10 +164,11 @@ const char *fastgrnn_hip_status_string(int status);
  *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are
  *                                 zero-extended to 16 inside the kernels): gates sigmoid / relu / tanh; all layout
  *                                 flags; backward under FASTGRNN_FLAG_SAVE_PREACT only.
- *   other factorised H=256, F=32 cells (a rank of 17..256, or only one of W, U factorised: rnn.py:783-798): the
- *                                 factors are multiplied out per call, the dense H=256 kernels run, the dense
- *                                 gradients are projected onto the factors (as the reference's CUDA operator does
- *                                 for every low-rank cell, .cu:353-362,546-555); that shape's limits apply.
+ *   every other factorised cell on one of the dense shapes above (H=128 with any ranks; H=256, F=32 with a rank of
+ *                                 17..256 or with only one of W, U factorised: rnn.py:783-798): the factors are
+ *                                 multiplied out per call, the dense kernels run, the dense gradients are
+ *                                 projected onto the factors (as the reference's CUDA operator does for every
+ *                                 low-rank cell, .cu:353-362,546-555); the dense shape's limits and flags apply.
  *                                 No rank-space vector is saved (c_s is ignored under FASTGRNN_FLAG_SAVE_PREACT).
  * Under FASTGRNN_FLAG_SAVE_PREACT a factorised forward with both ranks in 1..16 also writes, through c_s, the rank-space vector
  * [U1.h_{t-1} | W1.x_t] as a time-major fp32 [T*B, 32] tensor (each half zero-extended to 16 columns) that the

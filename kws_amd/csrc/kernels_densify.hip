@@ -1,16 +1,15 @@
-// Factorised cells that the register-resident low-rank scans do not cover (H = 256, F = 32 with a rank above 16, or
-// with only one of W, U factorised: rnn.py:783-798) on the DENSE H = 256 scans: W = W2.W1 and U = U2.U1 are
-// multiplied out once per call -- what the reference's CUDA operator does for every low-rank cell (.cu:353-362) --
-// the dense kernels of kernels_h256.hip run on them, and the backward projects the dense gradients onto the factors
-// (the chain rule the reference applies at .cu:546-555):  dW1 = W2^T dW,  dW2 = dW W1^T,  dU1 = U2^T dU,  dU2 = dU U1^T.
-// Four tiny GEMMs (<= 256 x 256 x 256, fp64 accumulation, one thread per output, fixed order) against scans of
-// hundreds of microseconds.  Same limits as the dense H = 256 path: fp32, time-major, gates sigmoid / relu / tanh.
+// Factorised cells that the register-resident low-rank scans do not cover (any rank on the dense shapes H = 128 with
+// F = 32 / 64 / 128 / 256; H = 256 / F = 32 with a rank above 16 or with only one of W, U factorised: rnn.py:783-798)
+// on the DENSE split-precision scans: W = W2.W1 and U = U2.U1 are multiplied out once per call -- what the reference's
+// CUDA operator does for every low-rank cell (.cu:353-362) -- the dense kernels run on them, and the backward projects
+// the dense gradients onto the factors (the chain rule the reference applies at .cu:546-555):
+// dW1 = W2^T dW,  dW2 = dW W1^T,  dU1 = U2^T dU,  dU2 = dU U1^T.  Tiny GEMMs (<= 256 x 256 x 256, fp64 accumulation, one
+// thread per output, fixed order) against scans of hundreds of microseconds.  The dense shape's own limits apply
+// (layouts, dtypes, gates, flags).
 #include "common.h"
 
 namespace fastgrnn {
 namespace {
-
-constexpr int H2 = 256, F2 = 32;
 
 // C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
 __global__ __launch_bounds__(256) void small_gemm(int M, int N, int K, const float* __restrict__ A, int sam, int sak,
@@ -35,14 +34,15 @@ fastgrnn_desc dense_desc(const fastgrnn_desc& d) {
 
 struct DenseWs { size_t wd, ud, dwd, dud, inner, total; };
 DenseWs layout(const fastgrnn_desc& d, bool backward) {
+  const size_t H2 = d.H, F2 = d.F;
   DenseWs L; size_t o = 0;
-  L.wd = o; o += align256((size_t)H2 * F2 * 4);
-  L.ud = o; o += align256((size_t)H2 * H2 * 4);
-  L.dwd = o; if (backward) o += align256((size_t)H2 * F2 * 4);
-  L.dud = o; if (backward) o += align256((size_t)H2 * H2 * 4);
+  L.wd = o; o += align256(H2 * F2 * 4);
+  L.ud = o; o += align256(H2 * H2 * 4);
+  L.dwd = o; if (backward) o += align256(H2 * F2 * 4);
+  L.dud = o; if (backward) o += align256(H2 * H2 * 4);
   L.inner = o;
   const fastgrnn_desc e = dense_desc(d);
-  o += backward ? h256_backward_ws(e) : h256_forward_ws(e);
+  o += backward ? split_backward_ws(e) : split_forward_ws(e);
   L.total = o;
   return L;
 }
@@ -50,6 +50,7 @@ DenseWs layout(const fastgrnn_desc& d, bool backward) {
 // the dense matrices of the cell: multiplied out into the workspace, or the caller's own where it is dense already
 void densify(const fastgrnn_desc& d, const fastgrnn_params& p, char* base, const DenseWs& L, fastgrnn_params& q,
              hipStream_t s) {
+  const int H2 = d.H, F2 = d.F;
   q = p;
   if (d.w_rank) {                                    // W[H,F] = W2[H,r] . W1[r,F]
     gemm(H2, F2, d.w_rank, (const float*)p.w2, d.w_rank, 1, (const float*)p.w1, F2, 1, (float*)(base + L.wd), s);
@@ -65,12 +66,13 @@ void densify(const fastgrnn_desc& d, const fastgrnn_params& p, char* base, const
 }  // namespace
 
 bool densified_shape(const fastgrnn_desc& d) {
-  return d.H == H2 && d.F == F2 && (d.w_rank > 0 || d.u_rank > 0) && d.w_rank <= H2 && d.u_rank <= H2 && !lowrank_shape(d);
+  return (d.w_rank > 0 || d.u_rank > 0) && d.w_rank <= d.H && d.u_rank <= d.H && !lowrank_shape(d) &&
+         ((d.H == 256 && d.F == 32) || (d.H == 128 && (d.F == 32 || d.F == 64 || d.F == 128 || d.F == 256)));
 }
 
 bool densified_supported(const fastgrnn_desc& d, int direction) {
-  const fastgrnn_desc e = dense_desc(d);
-  return h256_shape(e) && h256_supported(e, direction);
+  if (d.flags & FASTGRNN_FLAG_FWD_4WAVE) return false;
+  return split_supported(dense_desc(d), direction);
 }
 
 size_t densified_forward_ws(const fastgrnn_desc& d) { return layout(d, false).total; }
@@ -84,7 +86,7 @@ int densified_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const vo
   fastgrnn_params q;
   densify(d, p, base, L, q, s);
   // (under FASTGRNN_FLAG_SAVE_PREACT the dense contract saves the pre-activation alone: c_s is not used)
-  return h256_forward(dense_desc(d), q, x, h0, hs, zs, (d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? nullptr : cs, base + L.inner, s);
+  return split_forward(dense_desc(d), q, x, h0, hs, zs, (d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? nullptr : cs, base + L.inner, s);
 }
 
 int densified_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
@@ -98,8 +100,9 @@ int densified_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const v
   gd.d_w = d.w_rank ? (void*)(base + L.dwd) : g.d_w;
   gd.d_u = d.u_rank ? (void*)(base + L.dud) : g.d_u;
   gd.d_w1 = gd.d_w2 = gd.d_u1 = gd.d_u2 = nullptr;
-  const int st = h256_backward(dense_desc(d), q, ghs, x, hs, zs, cs, h0, gd, base + L.inner, s);
+  const int st = split_backward(dense_desc(d), q, ghs, x, hs, zs, cs, h0, gd, base + L.inner, s);
   if (st != FASTGRNN_OK) return st;
+  const int H2 = d.H, F2 = d.F;
   if (d.w_rank) {
     const float* dW = (const float*)(base + L.dwd);
     // dW1[r,F] = W2^T . dW :  A[m=i][k=h] = W2[h*r + i],  B[k=h][n=f] = dW[h*F + f]

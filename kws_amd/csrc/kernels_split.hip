@@ -1140,7 +1140,7 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (h256_shape(d)) return h256_supported(d, direction);      // dense H = 256 / F = 32: kernels_h256.hip
   if (lowrank_shape(d)) return lowrank_supported(d, direction); // H = 256 / F = 32, ranks <= 16: kernels_lowrank.hip
-  if (densified_shape(d)) return densified_supported(d, direction);   // the other factorised H = 256 cells: kernels_densify.hip
+  if (densified_shape(d)) return densified_supported(d, direction);   // every other factorised cell on a dense shape: kernels_densify.hip
   // dense H = 128 with a wider input (F = 64 / 128 / 256; the reference's second layer): recurrence-only scans +
   // batched GEMMs.  fp32 sequences, time- or batch-major, every gate, full or last-state outputs / gradients.
   if (dense_wide_shape(d)) {

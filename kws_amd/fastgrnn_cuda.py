@@ -205,7 +205,7 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
         hs = torch.empty((B, H) if hs_last else oshape, dtype=input.dtype, device=dev)
         zs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates or preact) else None
         cs = torch.empty(oshape, dtype=pdt, device=dev) if (want_gates and not preact) else None
-        if preact and 0 < desc.w_rank <= 16 and 0 < desc.u_rank <= 16:
+        if preact and desc.H == 256 and desc.F == 32 and 0 < desc.w_rank <= 16 and 0 < desc.u_rank <= 16:
             # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step, always
             # time-major and zero-extended to 16 + 16 columns (an opaque tensor for the backward)
             cs = torch.empty((T * B, 32), dtype=pdt, device=dev)
@@ -234,7 +234,8 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
             raise RuntimeError("FLAG_SAVE_PREACT backward needs bias_gate and bias_update")
         # (the register-resident low-rank scans, both ranks 1..16, save a rank-space vector; other factorised cells
         # run on the dense kernels and save the pre-activation alone)
-        rank_space = h_prime if (_present(w1) and _present(u1) and w1.shape[0] <= 16 and u1.shape[0] <= 16) else None
+        rank_space = h_prime if (_present(w1) and _present(u1) and w1.shape[0] <= 16 and u1.shape[0] <= 16
+                                 and tuple(w1.shape[1:]) == (32,) and u1.shape[1] == 256) else None
         if rank_space is not None:
             _check_input(rank_space, "rank_space")
             _expect(rank_space, (z.numel() // z.shape[-1], 32), "rank_space")

@@ -230,3 +230,45 @@ def test_module_with_rank_32_trains_on_the_matrix_pipe():
     assert fastgrnn_cuda.kernel_path(13, 40, F, H, 32, 32, 0, direction=1, flags=SAVE_PREACT) == 2
     m(x).square().mean().backward()
     assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters()) and x.grad is not None
+
+
+@pytest.mark.parametrize("Fi,Hi,rw,ru,B,flags", [(32, 128, 16, 16, 37, SAVE_PREACT), (32, 128, 8, None, 64, 0),
+                                                 (256, 128, 16, 16, 21, SAVE_PREACT), (32, 128, 4, 24, 48, SAVE_PREACT | BATCH_MAJOR)])
+def test_factorised_cells_on_the_dense_h128_kernels(Fi, Hi, rw, ru, B, flags):
+    """Factorised cells with H = 128 (any ranks; the register-resident low-rank scans are H = 256 only): multiplied out
+    per call onto the dense H = 128 kernels, with everything those offer (here: batch-major)."""
+    T = 10
+    rng = np.random.default_rng(7 + B)
+    p = O.make_params(Fi, Hi, rw, ru, dtype=np.float32, seed=31, randomize_scalars=True)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    x = rng.standard_normal((T, B, Fi)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, Hi))).astype(np.float32)
+    G = rng.standard_normal((T, B, Hi)).astype(np.float32)
+    bm = bool(flags & BATCH_MAJOR)
+    lay = (lambda a: np.ascontiguousarray(a.transpose(1, 0, 2))) if bm else (lambda a: a)
+    unlay = (lambda t: t.transpose(0, 1)) if bm else (lambda t: t)
+    for direction in (0, 1):
+        assert fastgrnn_cuda.kernel_path(T, B, Fi, Hi, rw or 0, ru or 0, 0, direction=direction, flags=flags) == 2
+    outs = fastgrnn_cuda.forward_unroll(_t(lay(x)), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), 0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
+    gr = fastgrnn_cuda.backward_unroll(_t(lay(G)), _t(lay(x)), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
+                                       P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64))
+    assert (np.abs(unlay(outs[0]).cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
+    g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64, h0.astype(np.float64),
+                            diagnostics=True)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: v for n, v in zip(names, gr) if v.numel()}
+    g["d_x"] = unlay(g["d_x"])
+    for k, v in g_o.items():
+        if k.startswith("_"):
+            continue
+        err = float(np.abs(g[k].cpu().numpy().reshape(v.shape) - v).max())
+        lim = 2e-5 * max(1.0, float(np.abs(v).max()))
+        if k in ("d_zeta", "d_nu"):
+            lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
+        assert err <= lim, (k, err, lim)

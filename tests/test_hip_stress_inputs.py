@@ -17,7 +17,7 @@ if torch.cuda.is_available():
 DEV = "cuda:0"
 
 FAMILIES = {"dense128": (32, 128, None), "wide256": (256, 128, None), "h256": (32, 256, None), "lowrank16": (32, 256, 16),
-            "rank32": (32, 256, 32)}
+            "rank32": (32, 256, 32), "lowrank_h128": (32, 128, 16)}
 SCENARIOS = ["big_weights", "tiny_weights", "saturated", "zeta_nu_extreme", "big_frames", "tiny_grad", "huge_grad",
              "zero_frames", "zero_grad", "two_steps", "sparse_weights"]
 
