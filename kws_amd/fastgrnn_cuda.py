@@ -152,6 +152,27 @@ def _plan(T, B, F, H, rw, ru, gate_nl, update_nl, dtype_code, flags):
             int(lib.fastgrnn_hip_backward_workspace_bytes(C.byref(desc))))
 
 
+_cliff_warned = set()
+
+
+def _warn_fallback(plan, direction):
+    """Perf cliffs are not silent: the first call of a shape that lands on the generic scan (kernel path 0) at a size
+    where that matters says so once (include/fastgrnn_hip.h lists what runs on the matrix pipe)."""
+    d = plan[0]
+    if plan[1 + direction] != 0 or d.T * d.B < 4096 or (d.flags & _lib.FLAG_FORCE_GENERIC):
+        return
+    key = (d.T, d.B, d.F, d.H, d.w_rank, d.u_rank, d.gate_nl, d.update_nl, d.dtype, d.flags, direction)
+    if key in _cliff_warned:
+        return
+    _cliff_warned.add(key)
+    import warnings
+    warnings.warn("fastgrnn: %s of shape T=%d B=%d F=%d H=%d ranks=(%d,%d) dtype=%d flags=0x%x runs on the generic "
+                  "scan (kernel path 0), typically 20-30x slower than the matrix-pipe kernels; see "
+                  "include/fastgrnn_hip.h (fastgrnn_hip_kernel_path) for the shapes those cover"
+                  % ("backward" if direction else "forward", d.T, d.B, d.F, d.H, d.w_rank, d.u_rank, d.dtype, d.flags),
+                  RuntimeWarning, stacklevel=4)
+
+
 def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -194,6 +215,7 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
     plan, params, _, _ = _describe(T, B, F, H, w, u, w1, w2, u1, u2, bias_gate, bias_update, zeta, nu,
                                    input.dtype, gate_nl, update_nl, flags)
     desc = plan[0]
+    _warn_fallback(plan, 0)
     dev = input.device
     oshape = ((B, T, H) if batch_major else (T, B, H)) if unrolled else (B, H)
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
@@ -272,6 +294,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                                          bias_gate if preact else zeta, bias_update if preact else zeta,
                                          zeta, nu, dt, gate_nl, update_nl, flags)
     desc = plan[0]
+    _warn_fallback(plan, 1)
     dev = input.device
     with torch.cuda.device(dev):
         mk = lambda *s: torch.empty(s, dtype=pdt, device=dev)

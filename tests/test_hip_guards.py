@@ -226,3 +226,22 @@ def test_weights_whose_blocks_sit_in_different_binades(H, F, r):
         if k in ("d_zeta", "d_nu"):
             lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
         assert err <= lim, (k, err, lim)
+
+
+def test_fallback_to_the_generic_scan_warns_once():
+    """A shape without matrix-pipe kernels (H = 100) at a size where it matters: one RuntimeWarning per shape and
+    direction, none for shapes that are covered or too small to matter."""
+    import warnings
+    e = torch.empty(0)
+    def fwd(T, B, F, H):
+        p = O.make_params(F, H, dtype=np.float32, seed=1)
+        x = torch.zeros(T, B, F, device=DEV); h0 = torch.zeros(B, H, device=DEV)
+        return fastgrnn_cuda.forward_unroll(x, _t(p["w"]), _t(p["u"]), _t(p["bias_gate"]), _t(p["bias_update"]), _t(p["zeta"]),
+                                            _t(p["nu"]), h0, 0, e, e, e, e, want_gates=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        fwd(64, 128, 20, 100); fwd(64, 128, 20, 100)            # path 0, T*B = 8192
+        fwd(64, 128, 32, 128)                                   # path 2
+        fwd(4, 8, 20, 100)                                      # path 0 but tiny
+    msgs = [str(m.message) for m in w if issubclass(m.category, RuntimeWarning) and "generic scan" in str(m.message)]
+    assert len(msgs) == 1 and "H=100" in msgs[0]
