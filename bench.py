@@ -301,6 +301,8 @@ def main():
             "roofline": {"kernel": "backward_unroll", "bound": "hbm",
                          "achieved": B * BYTES_BWD / (avg_b * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": B * BYTES_BWD / (avg_b * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "workload (tools/profile.sh; counters cannot be read from inside the run)",
                          "avg_launch_ms": avg_b, "bytes_per_launch": B * BYTES_BWD,
                          "moved_gbs": (B * BYTES_BWD_PREACT / (avg_b * 1e-3) / 1e9) if split else None},
             "roofline_mfma": {"kernel": "backward_unroll", "bound": "mfma", "achieved": tf_b, "peak": PEAK_F32_TFLOPS,
