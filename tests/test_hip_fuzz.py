@@ -1,0 +1,107 @@
+"""GPU fuzz test: seeded random (shape family, T, B, gate, layout flags, last-state contract, weight / state / gradient
+scales per BLOCK) against the fp64 oracle.  The hand-written parity tests each fix one aspect and draw the rest from
+one distribution; a defect that needs two unusual things at once (round 2: a per-block scale x a weight matrix whose
+blocks differ) goes through them.  The bounds are those of a smoke detector (2e-5 / 5e-5 of the largest element, or
+four times what the oracle itself loses in fp32 on an expansive draw), not the parity bounds of the other files.  Smooth gates only (sigmoid, tanh): the piecewise-linear ones need the same-mask
+comparison of their own tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fastgrnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from kws_amd import _lib, fastgrnn_cuda
+DEV = "cuda:0"
+FAMILIES = [(32, 128, None, None), (64, 128, None, None), (256, 128, None, None), (32, 256, None, None), (32, 256, 16, 16),
+            (32, 256, 7, 12), (32, 256, 32, 20), (32, 128, 8, 8), (32, 256, None, 16), (128, 128, 16, None)]
+SAVE_PREACT, BATCH_MAJOR, X_BFT, GRAD_LAST = 4, 16, 128, 256
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _block_scale(rng, n, lo=-3, hi=2):
+    """a factor per 16-block, powers of two times a mantissa, spread over 2^lo .. 2^hi"""
+    nb = (n + 15) // 16
+    f = (2.0 ** rng.integers(lo, hi + 1, nb)) * rng.uniform(0.6, 1.0, nb)
+    return np.repeat(f, 16)[:n].astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", "120"))))
+def test_random_configuration_against_the_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    F, H, rw, ru = FAMILIES[seed % len(FAMILIES)]
+    T = int(rng.integers(1, 19)); B = int(rng.choice([1, 5, 16, 17, 33, 48, 63]))
+    gate = ["sigmoid", "tanh"][int(rng.integers(0, 2))]
+    gcode = {"sigmoid": 0, "tanh": 2}[gate]
+    p = O.make_params(F, H, rw, ru, dtype=np.float32, seed=seed, randomize_scalars=True)
+    for k in ("w", "u", "w2", "u2"):                       # rows in blocks
+        if k in p:
+            p[k] = (p[k] * _block_scale(rng, p[k].shape[0])[:, None]).astype(np.float32)
+    for k in ("u", "u1"):                                  # columns in blocks
+        if k in p:
+            p[k] = (p[k] * _block_scale(rng, p[k].shape[1], -2, 1)[None, :]).astype(np.float32)
+    if gate == "tanh":                                     # a tanh gate is not contractive: keep the recurrence tame
+        for k in ("u", "u2"):
+            if k in p:
+                p[k] = (0.3 * p[k]).astype(np.float32)
+    p["zeta"] = np.asarray([[rng.uniform(-3, 3)]], np.float32); p["nu"] = np.asarray([[rng.uniform(-6, 1)]], np.float32)
+    x = (rng.standard_normal((T, B, F)) * 2.0 ** rng.integers(-3, 3)).astype(np.float32)
+    h0 = (rng.standard_normal((B, H)) * rng.choice([0.0, 0.5, 3.0])).astype(np.float32)
+    G = (rng.standard_normal((T, B, H)) * 10.0 ** rng.integers(-4, 3)).astype(np.float32)
+    flags = SAVE_PREACT
+    want = []
+    if rng.random() < 0.5: want.append(BATCH_MAJOR)
+    if rng.random() < 0.3: want.append(X_BFT)
+    if rng.random() < 0.3: want.append(GRAD_LAST)
+    for f in want:                                         # keep the flags this shape has kernels for
+        if all(fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, gcode, direction=d, flags=flags | f) == 2 for d in (0, 1)):
+            flags |= f
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, gcode, direction=1, flags=flags) == 2
+    bm, bft, gl = bool(flags & BATCH_MAJOR), bool(flags & X_BFT), bool(flags & GRAD_LAST)
+    if gl:
+        G[:-1] = 0.0
+    lay = (lambda a: np.ascontiguousarray(a.transpose(1, 0, 2))) if bm else (lambda a: a)
+    unlay = (lambda t: t.transpose(0, 1)) if bm else (lambda t: t)
+    xi = np.ascontiguousarray(x.transpose(1, 2, 0)) if bft else lay(x)
+    Gi = G[-1] if gl else lay(G)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    outs = fastgrnn_cuda.forward_unroll(_t(xi), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), gcode,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], flags=flags & ~GRAD_LAST)
+    gr = fastgrnn_cuda.backward_unroll(_t(Gi), _t(xi), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
+                                       P["w1"], P["w2"], P["u1"], P["u2"], gcode, flags=flags,
+                                       bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
+    tag = (seed, F, H, rw, ru, T, B, gate, hex(flags))
+    hs = unlay(outs[0]).cpu().numpy()
+    # block factors up to 4 make some draws expansive: every bound is the usual one or three times what the oracle
+    # itself loses when it is run in fp32 (numpy), whichever is larger
+    hs_32, zs_32, cs_32 = O.unroll_forward(x, p, h0, gate=gate)
+    rel = lambda a: float((np.abs(a - hs_o) / np.maximum(1.0, np.abs(hs_o))).max())
+    assert rel(hs) <= max(2e-5, 4.0 * rel(hs_32)), (tag, rel(hs), rel(hs_32))
+    g_32 = O.unroll_backward(G, x, hs_32, zs_32, cs_32, p, h0, gate=gate)
+    g_o = O.unroll_backward(G.astype(np.float64), x.astype(np.float64), hs_o, zs_o, cs_o, p64, h0.astype(np.float64), gate=gate,
+                            diagnostics=True)
+    names = ["d_x", "d_bias_gate", "d_bias_update", "d_zeta", "d_nu", "d_h0", "d_w", "d_u", "d_w1", "d_w2", "d_u1", "d_u2"]
+    g = {n: v for n, v in zip(names, gr) if v.numel()}
+    g["d_x"] = g["d_x"].permute(2, 0, 1) if bft else unlay(g["d_x"])
+    gscale = float(np.abs(G).max())
+    for k, v in g_o.items():
+        if k.startswith("_"):
+            continue
+        got = g[k].cpu().numpy().reshape(v.shape)
+        err = float(np.abs(got - v).max())
+        lim = max(5e-5 * float(np.abs(v).max()), 1e-6 * gscale)
+        if k in ("d_zeta", "d_nu"):
+            lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
+        lim = max(lim, 4.0 * float(np.abs(g_32[k].reshape(v.shape) - v).max()))
+        assert np.isfinite(got).all() and err <= lim, (tag, k, err, lim)
