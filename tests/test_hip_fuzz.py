@@ -105,3 +105,64 @@ def test_random_configuration_against_the_oracle(seed):
             lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
         lim = max(lim, 4.0 * float(np.abs(g_32[k].reshape(v.shape) - v).max()))
         assert np.isfinite(got).all() and err <= lim, (tag, k, err, lim)
+
+
+GATES = ["sigmoid", "relu", "tanh", "quantTanh", "quantSigm", "quantSigm4"]
+HS_LAST = 512
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", "120"))))
+def test_random_forward_all_gates_dtypes_and_last_state(seed):
+    """Forward only (no derivative jumps to worry about): all six gates, bf16 or fp32 sequences, full hs or h_T alone,
+    the layouts each shape offers, block-scaled weights."""
+    rng = np.random.default_rng(50000 + seed)
+    F, H, rw, ru = FAMILIES[seed % len(FAMILIES)]
+    T = int(rng.integers(1, 19)); B = int(rng.choice([1, 5, 16, 17, 33, 48, 63]))
+    gate = GATES[int(rng.integers(0, 6))]
+    gcode = GATES.index(gate)
+    p = O.make_params(F, H, rw, ru, dtype=np.float32, seed=seed, randomize_scalars=True)
+    for k in ("w", "u", "w2", "u2"):
+        if k in p:
+            p[k] = (p[k] * _block_scale(rng, p[k].shape[0], -3, 1)[:, None]).astype(np.float32)
+    if gate in ("relu", "tanh", "quantTanh"):              # gates that do not bound the state: keep it tame
+        for k in ("u", "u2"):
+            if k in p:
+                p[k] = (0.3 * p[k]).astype(np.float32)
+        p["bias_gate"] = (0.3 * p["bias_gate"] - 0.1).astype(np.float32)
+    bf16 = rng.random() < 0.35
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = (rng.standard_normal((T, B, F)) * 2.0 ** rng.integers(-2, 2)).astype(np.float32)
+    h0 = (rng.standard_normal((B, H)) * rng.choice([0.0, 0.5])).astype(np.float32)
+    xt = torch.from_numpy(x).to(dt)
+    x_used = xt.to(torch.float64).numpy()
+    flags = 0
+    for f in [q for q, pr in ((BATCH_MAJOR, 0.4), (X_BFT, 0.25), (HS_LAST, 0.35)) if rng.random() < pr]:
+        if fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, gcode, dtype=dt, direction=0, flags=flags | f) == 2:
+            flags |= f
+    if fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, gcode, dtype=dt, direction=0, flags=flags) != 2:
+        pytest.skip("no matrix-pipe forward for this draw")
+    bm, bft, last = bool(flags & BATCH_MAJOR), bool(flags & X_BFT), bool(flags & HS_LAST)
+    xi = xt.permute(1, 2, 0).contiguous() if bft else (xt.transpose(0, 1).contiguous() if bm else xt)
+    e = torch.empty(0)
+    P = {k: e for k in ("w", "u", "w1", "w2", "u1", "u2")}
+    P.update({k: _t(v) for k, v in p.items()})
+    hs = fastgrnn_cuda.forward_unroll(xi.to(DEV), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), gcode,
+                                      P["w1"], P["w2"], P["u1"], P["u2"], want_gates=False, flags=flags)[0]
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    hs_o, _, _ = O.unroll_forward(x_used, p64, h0.astype(np.float64), gate=gate)
+    hs_32, _, _ = O.unroll_forward(x_used.astype(np.float32), p, h0, gate=gate)
+    got = hs.to(torch.float64).cpu().numpy()
+    if last:
+        ref, ref32 = hs_o[-1], hs_32[-1]
+    else:
+        got = got.transpose(1, 0, 2) if bm else got
+        ref, ref32 = hs_o, hs_32
+    rel = lambda a: float((np.abs(a - ref) / np.maximum(1.0, np.abs(ref))).max())
+    lim = max(2e-5, 4.0 * rel(ref32)) + (2.0 ** -8 if bf16 else 0.0)
+    tag = "seed=%d F=%d H=%d ranks=%s/%s T=%d B=%d gate=%s bf16=%s flags=%s ref_finite=%s got_finite=%s" % (
+        seed, F, H, rw, ru, T, B, gate, bf16, hex(flags), bool(np.isfinite(ref).all()), bool(np.isfinite(got).all()))
+    if not (np.isfinite(ref).all() and np.isfinite(ref32).all()):
+        pytest.skip("the draw overflows fp32 (a relu gate multiplies the state by z > 1 every frame): " + tag)
+    if gate == "relu":                                     # expansive by construction: a wider band around fp32's own loss
+        lim = max(lim, 8.0 * rel(ref32))
+    assert np.isfinite(got).all() and rel(got) <= lim, (tag, rel(got), lim)
