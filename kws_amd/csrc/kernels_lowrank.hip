@@ -110,9 +110,11 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
       if (AUX == 1) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
-      } else if (AUX == 2) {
+      } else if (AUX == 2 || AUX == 3) {             // (3: the rank-space vector alone -- the backward recomputes the
+        if (AUX == 2) {                              //  pre-activation from it, bwd_scan_lowrank_split<.., RECOMP>)
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);      // gt.z carries the pre-activation
+          for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);    // gt.z carries the pre-activation
+        }
         // [m_h | m_x] of the step: cs is [T,B,32] in this mode; every wave holds the same sum, wave w
         // stores lane groups g == w (8 floats each)
         if (g == wv) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
         mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
       }
     }
-    if (AUX == 2) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
+    if (AUX == 2 || AUX == 3) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
     const Frag3 mB = split3(mlo, mhi);
     // ---- B: pre-activation tiles, epilogue of tile k under the MFMAs of tile k+1 -----------------
     f32x4 acc[NT];
@@ -237,10 +239,15 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
 // gradient of the last state only (FASTGRNN_FLAG_GRAD_LAST).  BF: grad_hs, hs and d_x are bf16 (h0, pre_s fp32).
 constexpr int SLAB_LR = 576;   // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded to 64
 
-template <int GATE, bool RAGGED, bool BF = false, int NW = 8>
+// RECOMP: pre_s is NULL and the pre-activation of step t is recomputed from the rank-space vector the forward saved,
+// pre = [U2|W2] . [m_h ; m_x] -- the forward's own second product (one K-step, six MFMA terms per row tile, same
+// operands in the same order: the same bits) with the [U2|W2] fragments parked in LDS.  Config 4 moves 3.8 GB per step
+// at 4.6 TB/s; the saved pre-activation is 0.83 GB of that (written by the forward, read here).
+template <int GATE, bool RAGGED, bool BF = false, bool RECOMP = false, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     int Tn, int B, int rsT, int rsB, int xsT, int xsB, int rw, int ru, int glast,
     const float* __restrict__ ghs, const float* __restrict__ hs, const float* __restrict__ pre_s,
+    const float* __restrict__ m_s,
     const float* __restrict__ h0, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ u1, const float* __restrict__ u2,
     const float* __restrict__ bz, const float* __restrict__ bh,
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
   __shared__ __attribute__((aligned(16))) float sbias[2][H];
   __shared__ float red[2 * NW];
+  __shared__ __attribute__((aligned(16))) u32x4 uw2l[RECOMP ? NW * NT * 3 * 64 : 1];   // [U2|W2] fragments, per wave
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -313,12 +321,32 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
     W1Tf = split3(lo, hi);
   }
 
+  if (RECOMP) {                                    // rows = own units; K = [m_h rows 8g.. | m_x rows 8(g-2)..]: as the forward
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      const int nA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
+      const int rk = g < 2 ? ru : rw, j0 = g < 2 ? 8 * g : 8 * (g - 2);
+      const float* pf = (g < 2 ? u2 : w2) + (size_t)nA * rk;
+      f32x4 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = j0 + j < rk ? pf[j0 + j] : 0.f;
+        hi[j] = j0 + 4 + j < rk ? pf[j0 + 4 + j] : 0.f;
+      }
+      const Frag3 f = split3(lo, hi);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) uw2l[((wv * NT + mt) * 3 + pl) * 64 + l] = f.p[pl];
+    }
+  }
+
   f32x4 sbz[NT], sbh[NT], dh[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
   float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;     // d_zeta / d_nu partial sums, compensated
 
-  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };   // grad_hs, pre-activation, h_prev (own 16 units)
+  // grad_hs, pre-activation (RECOMP: a0[0], a0[1] carry the 8 rank-space values of this lane's K rows), h_prev
+  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };
+  static_assert(!RECOMP || NT == 2, "the recomputation parks the rank-space fragment in a0[0..1]");
   // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
   // of a 64-bit pointer pair each (the host rejects B*H*4 >= 2^31 for this path).
   const unsigned lane_h = (unsigned)bc * rsB * H + n0, lane_0 = (unsigned)bc * H + n0;
@@ -353,13 +381,39 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       e.g[mt] = gzero ? f32x4{0.f, 0.f, 0.f, 0.f}
                       : ld4s(BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(ghs) + gstep) : ghs + gstep,
                              lane_g + 4 * mt);
-      e.a0[mt] = ld4(pt + lane_h + 4 * mt);
+      if (RECOMP) e.a0[mt] = ld4(m_s + ((size_t)t * B + bc) * 32 + 8 * g + 4 * mt);   // rows 8g.. of [m_h ; m_x], time-major
+      else e.a0[mt] = ld4(pt + lane_h + 4 * mt);
       if (t == 0) e.h[mt] = ld4(h0 + lane_0 + 4 * mt);                       // .cu:478-481
       else e.h[mt] = ld4s(BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(hs) + hstep) : hs + hstep,
                           lane_h + 4 * mt);
     }
   };
 
+  // RECOMP: e.a0 arrives holding this lane's 8 rank-space values and leaves holding the pre-activation of the own units.
+  // Two parts, because the fragments must be in registers of their own BEFORE any MFMA that is still in flight when
+  // they are requested (operand rule): recomp_prep reads them (and splits the rank-space values), recomp_issue runs
+  // the products and ends with their completion read.
+  struct Recomp { Frag3 Uf[NT], mBf; };
+  auto recomp_prep = [&](const EwOps& e, Recomp& rc) __attribute__((always_inline)) {
+    rc.mBf = split3(e.a0[0], e.a0[1]);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rc.Uf[mt].p[pl] = uw2l[((wv * NT + mt) * 3 + pl) * 64 + l];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto recomp_issue = [&](EwOps& e, const Recomp& rc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) e.a0[mt] = mfma6(rc.Uf[mt], rc.mBf, f32x4{0.f, 0.f, 0.f, 0.f});  // rnn.py:281,287,289
+    __builtin_amdgcn_sched_barrier(0);
+    // completion read HERE: the next step's first instructions are LDS reads (the biases) that the compiler would
+    // otherwise land in the fragments' dead registers right behind the MFMAs (operand rule; the scanner found it)
+    float touch = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) touch += e.a0[mt][0];
+    if (touch == 1.2345678e38f) red[1] = 1.f;
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const int cur = t & 1;
     {
@@ -430,6 +484,8 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       *reinterpret_cast<f32x4*>(mo) = mlo; *reinterpret_cast<f32x4*>(mo + 16) = mhi;
     }
     const Frag3 mB = split3(mlo, mhi);
+    Recomp rc;
+    if (RECOMP && t > 0) recomp_prep(e, rc);         // (fragments of the NEXT step's pre-activation: requested before the products below)
     // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
     f32x4 dlo[NT];
 #pragma unroll
@@ -443,6 +499,9 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
         if (BF) st4_bf16(o, dxv); else *reinterpret_cast<f32x4*>(o) = dxv;
       }
     }
+    // RECOMP: the next step's pre-activation now, behind this step's last products in the matrix pipe (at the top of
+    // the next step it is a dependent phase of ~350 cycles in front of EW: +34 us per launch, measured)
+    if (RECOMP && t > 0) recomp_issue(e, rc);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
   };
@@ -450,6 +509,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   EwOps ea;                                          // ONE operand set, refilled right behind its use (see step)
   __syncthreads();                                   // sbias
   load_ew(Tn - 1, ea);
+  if (RECOMP) { Recomp rc0; recomp_prep(ea, rc0); recomp_issue(ea, rc0); }
   for (int t = Tn - 1; t >= 0; --t) step(t, ea);
   {
     // the last step's MFMAs have retired before anything below (stores masked by `valid`, the reductions' LDS
@@ -817,14 +877,20 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 0, s, d.T, d.B, rsT, rsB, xsT, xsB, d.w_rank, d.u_rank,
                        (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 1 : 0, (const float*)ghs, (const float*)hs,
-                       (const float*)pre_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
+                       (const float*)pre_s, (const float*)m_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
                        (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate, (const float*)p.bias_update,
                        (const float*)p.zeta, (const float*)p.nu, (float*)dxs, (float*)g.d_h0, dpre, dm, part);
   };
   // 8 waves (two per SIMD) for full and ragged batches alike (lanes beyond a ragged batch only get a zero gradient,
   // which needs no extra registers; the first ragged variant masked five values per element and spilled)
-  if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true>); }
-  else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false>); else go(bwd_scan_lowrank_split<GATE, false, false>); }
+  // pre_s == NULL: the pre-activation is recomputed from the rank-space vector (the forward then did not store it)
+  if (pre_s) {
+    if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true>); }
+    else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false>); else go(bwd_scan_lowrank_split<GATE, false, false>); }
+  } else {
+    if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true, true>); }
+    else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false, true>); else go(bwd_scan_lowrank_split<GATE, false, false, true>); }
+  }
   if (bft) {
     if (bf) hipLaunchKernelGGL((bft_transpose<unsigned short, false>), dim3(d.B), dim3(256), 0, s, d.B, d.T,
                                (const unsigned short*)(base + L.dxt), (unsigned short*)g.d_x);
@@ -880,13 +946,17 @@ void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta, (const float*)p.nu,
                        (float*)hs, (float*)zs, (float*)cs);
   };
-  const int aux = zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1);
+  // SAVE_PREACT with z_s == NULL: only the rank-space vector is saved (the backward recomputes the pre-activation)
+  const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  const int aux = zs == nullptr ? ((preact && cs) ? 3 : 0) : (preact ? 2 : 1);
   auto pick = [&](auto bf_tag) __attribute__((always_inline)) {
     constexpr bool BFv = decltype(bf_tag)::value;
     if (d.flags & FASTGRNN_FLAG_HS_LAST) {           // inference: aux == 0 (lowrank_forward)
       if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, BFv, true>); else go(fwd_scan_lowrank_split<GATE, 0, false, BFv, true>);
     } else if (aux == 2) {
       if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 2, false, BFv>);
+    } else if (aux == 3) {
+      if (ragged) go(fwd_scan_lowrank_split<GATE, 3, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 3, false, BFv>);
     } else if (aux == 0) {
       if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 0, false, BFv>);
     } else if constexpr (!BFv) {                     // the reference's (z_s, h_prime_s) outputs: fp32 sequences
@@ -926,8 +996,8 @@ size_t lowrank_backward_ws(const fastgrnn_desc& d) { return lowrank_bwd_layout(d
 int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
                     void* cs, void* ws, hipStream_t s) {
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  if (preact && (!zs || !cs)) return FASTGRNN_ERR_NULL_POINTER;
-  if ((d.flags & FASTGRNN_FLAG_HS_LAST) && zs) return FASTGRNN_ERR_UNSUPPORTED;
+  if (preact && !cs) return FASTGRNN_ERR_NULL_POINTER;   // (z_s may be NULL: the rank-space vector alone is saved)
+  if ((d.flags & FASTGRNN_FLAG_HS_LAST) && (zs || (preact && cs))) return FASTGRNN_ERR_UNSUPPORTED;
   if (d.dtype == FASTGRNN_BF16_IO && zs && !preact) return FASTGRNN_ERR_UNSUPPORTED;
   if ((d.flags & FASTGRNN_FLAG_X_BFT) && !ws) return FASTGRNN_ERR_WORKSPACE;
   switch (d.gate_nl) {

@@ -272,3 +272,43 @@ def test_factorised_cells_on_the_dense_h128_kernels(Fi, Hi, rw, ru, B, flags):
         if k in ("d_zeta", "d_nu"):
             lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
         assert err <= lim, (k, err, lim)
+
+
+@pytest.mark.parametrize("B,rw,ru,bf16,bm", [(64, 16, 16, False, False), (37, 16, 16, False, False), (48, 8, 12, False, True),
+                                             (33, 16, 16, True, False), (4096, 16, 16, False, False)])
+def test_backward_recomputes_the_preactivation_bit_for_bit(B, rw, ru, bf16, bm):
+    """forward_unroll(..., keep_preact=False) stores the rank-space vector alone (z_s = NULL in the C ABI); the backward
+    recomputes the pre-activation from it with the forward's own product -- same operands, same order -- so every
+    gradient equals the run that kept the [T,B,H] tensor, bit for bit."""
+    T = 99 if B == 4096 else 17
+    _, P = _params(rw, ru, seed=12)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(5 + B)
+    x = torch.randn(T, B, F, generator=g).to(dt).to(DEV)
+    G = torch.randn(T, B, H, generator=g).to(dt).to(DEV)
+    h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
+    if bm:
+        x, G = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
+    fl = SAVE_PREACT | (BATCH_MAJOR if bm else 0)
+    args = (x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])
+    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    o_k = fastgrnn_cuda.forward_unroll(*args, flags=fl)
+    g_k = fastgrnn_cuda.backward_unroll(G, x, o_k[0], P["zeta"], P["nu"], P["w"], P["u"], o_k[1], o_k[2], h0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
+    # same hs, same rank-space vector, no pre-activation tensor: the recomputed one must give the same bits
+    none = torch.empty(0, device=DEV)
+    g_r = fastgrnn_cuda.backward_unroll(G, x, o_k[0], P["zeta"], P["nu"], P["w"], P["u"], none, o_k[2], h0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
+    for k, (a, b) in enumerate(zip(g_k, g_r)):
+        assert torch.equal(a, b), k
+    # the forward that stores the rank-space vector alone is another instantiation of the kernel: equal to fp32 rounding
+    o_n = fastgrnn_cuda.forward_unroll(*args, flags=fl, keep_preact=False)
+    assert o_n[1].numel() == 0
+    tol = 2.0 ** -7 if bf16 else 2e-6
+    assert float((o_k[0].float() - o_n[0].float()).abs().max()) <= tol
+    assert float((o_k[2] - o_n[2]).abs().max()) <= 2e-6 * max(1.0, float(o_k[2].abs().max()))
+    g_n = fastgrnn_cuda.backward_unroll(G, x, o_n[0], P["zeta"], P["nu"], P["w"], P["u"], o_n[1], o_n[2], h0,
+                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
+    for k, (a, b) in enumerate(zip(g_k, g_n)):
+        if a.numel():
+            assert float((a.float() - b.float()).abs().max()) <= (2.0 ** -6 if bf16 else 2e-5) * max(1.0, float(a.float().abs().max())), k
