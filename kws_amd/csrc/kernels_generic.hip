@@ -111,14 +111,16 @@ __global__ __launch_bounds__(NTHREADS) void fwd_scan_generic(
         T z = act<T>(pre + bzn, gate);                   // rnn.py:290
         T c = act<T>(pre + bhn, upd);                    // rnn.py:292
         T hv = z * hc[b * H + n] + (sz * (T(1) - z) + sn) * c;   // rnn.py:294-295
-        hn[b * H + n] = hv;
         if (b0 + b < B) {
           size_t o = ((size_t)t * B + b0 + b) * H + n;
           hs[o] = hv;
           if (zs) zs[o] = z;
           if (cs) cs[o] = c;
         }
+        hn[b * H + n] = hv;      // (behind the conditional stores: no LDS write in front of a branch with memory
+                                 //  instructions behind it -- DESIGN.md 4.0, tools/lds_branch_vmem_scan.py)
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
     cur ^= 1;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(NTHREADS) void bwd_scan_generic(
   for (int t = Tn - 1; t >= 0; --t) {
     for (int n = tid; n < H; n += nth) {
       T az = 0, ah = 0;
+      T dpa[BT], zga[BT];
 #pragma unroll
       for (int b = 0; b < BT; ++b) {
         T dpv = 0, zg = 0;
@@ -177,10 +180,14 @@ __global__ __launch_bounds__(NTHREADS) void bwd_scan_generic(
           zg = z * g;                                                      // .cu:108
           dpre_out[o] = dpv;
         }
-        dp[b * H + n] = dpv;
-        dh[b * H + n] = zg;
+        dpa[b] = dpv; zga[b] = zg;
       }
+      // the LDS writes behind all conditional loads / stores of this unit, and waited for before the loop's branch:
+      // no LDS write in front of a branch with memory instructions behind it (lds_branch_vmem_scan.py)
+#pragma unroll
+      for (int b = 0; b < BT; ++b) { dp[b * H + n] = dpa[b]; dh[b * H + n] = zga[b]; }
       sbz[n] += az; sbh[n] += ah;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (ru) {
