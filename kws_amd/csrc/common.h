@@ -102,6 +102,7 @@ int h256_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
                   const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s);
 
 // low-rank H = 256 / F = 32 scans, ranks <= 16 (kernels_lowrank.hip), dispatched like the H = 256 dense ones
+void bft_transpose_f32(int B, int T, const float* src, float* dst, bool to_time_major, hipStream_t s);
 bool lowrank_shape(const fastgrnn_desc& d);
 bool lowrank_supported(const fastgrnn_desc& d, int direction);
 size_t lowrank_forward_ws(const fastgrnn_desc& d);

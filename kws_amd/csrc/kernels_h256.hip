@@ -45,7 +45,8 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags) {
+    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags,
+    unsigned xs_b, unsigned xs_f, unsigned xs_t) {
   constexpr bool F16H = MODE == 1;
   if (MODE == 2 && flags[blockIdx.x] == 0u) return;  // (whole workgroup; no barrier has been passed)
   // One byte array carved per path (static LDS is the maximum over both):
@@ -182,8 +183,10 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     *reinterpret_cast<unsigned short*>(xpl + PLX2 + off) = s1;
     *reinterpret_cast<unsigned short*>(xpl + 2 * PLX2 + off) = s2;
   };
-  const float* xlane = x + (size_t)xbc * F2 + xf;          // this lane's value of frame t: xlane[t * B * F]
-  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * B * F2]; };
+  // this lane's value of frame t: xlane[t * xs_t].  x is [T,B,F] (xs_b = F, xs_f = 1, xs_t = B*F) or, under
+  // FASTGRNN_FLAG_X_BFT, the data loader's [B,F,T] read in place (xs_b = F*T, xs_f = T, xs_t = 1: trainClassifier.py:204)
+  const float* xlane = x + (size_t)xbc * xs_b + (size_t)xf * xs_f;
+  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * xs_t]; };
   const unsigned lane_hs = (unsigned)b * H2 + n0;
   auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(1024) void reduce_h256_small(int nwg, const float* 
   }
 }
 
-struct H256BwdWs { size_t part, dpre, tn, total; };
+struct H256BwdWs { size_t part, dpre, tn, xtm, total; };
 H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   H256BwdWs L; size_t o = 0;
@@ -658,6 +661,9 @@ H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
   L.dpre = o; o += align256((TB + 16) * H2 * 4);     // + 16 sink rows for the lanes beyond a ragged batch
   const size_t tn_u = tn_gemm_big_ws(TB, H2, H2), tn_w = tn_gemm_big_ws(TB, H2, F2);
   L.tn = o; o += tn_u > tn_w ? tn_u : tn_w;
+  // FASTGRNN_FLAG_X_BFT: the time-major copy of x for the dW GEMM; the d_x GEMM then writes over it and the result is
+  // transposed into the caller's [B,F,T] tensor
+  L.xtm = o; if (d.flags & FASTGRNN_FLAG_X_BFT) o += align256(TB * F2 * 4);
   L.total = o;
   return L;
 }
@@ -669,10 +675,13 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
   const bool ragged = (d.B % 16) != 0;
   const int aux = (d.flags & FASTGRNN_FLAG_HS_LAST) ? 3 : (zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1));
   unsigned* flags = reinterpret_cast<unsigned*>(ws);
+  const bool bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
+  const unsigned xs_b = bft ? (unsigned)(F2 * d.T) : (unsigned)F2, xs_f = bft ? (unsigned)d.T : 1u;
+  const unsigned xs_t = bft ? 1u : (unsigned)(d.B * F2);
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
-                       (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags);
+                       (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags, xs_b, xs_f, xs_t);
   };
   // fp16 two-plane state product only for gates that keep z in [0,1] (see fwd_scan_split_w8); FWD_BF16X3: A/B
   constexpr bool BOUNDED = GATE == FASTGRNN_NL_SIGMOID || GATE == FASTGRNN_NL_QUANT_SIGM || GATE == FASTGRNN_NL_QUANT_SIGM4;
@@ -715,10 +724,17 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
   const size_t TB = (size_t)d.T * d.B;
   // dU = d_pre^T . H_prev (rows of t = 0 are h0, the rest hs[t-1]);  dW = d_pre^T . X   (.cu:539-540 over all steps)
   tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
-  tn_gemm_big_run(TB, H2, F2, dpre, H2, (const float*)x, (const float*)x, (size_t)0, F2, tn, (float*)g.d_w, F2, s);
+  const bool bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
+  float* xtm = (float*)(base + L.xtm);
+  if (bft) bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
+  const float* xr = bft ? xtm : (const float*)x;
+  tn_gemm_big_run(TB, H2, F2, dpre, H2, xr, xr, (size_t)0, F2, tn, (float*)g.d_w, F2, s);
   // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N]); skipped when the caller does not want the input's gradient
   // (g.d_x == NULL: the first layer of a model, whose input is data)
-  if (g.d_x) rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, g.d_x, false, false, s);
+  if (g.d_x) {
+    rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, bft ? (void*)xtm : g.d_x, false, false, s);
+    if (bft) bft_transpose_f32(d.B, d.T, xtm, (float*)g.d_x, false, s);
+  }
 }
 
 }  // namespace
@@ -731,7 +747,9 @@ bool h256_shape(const fastgrnn_desc& d) {
 // time-major fp32 sequences, every gate, both saved-tensor contracts, full or last-state outputs / gradients
 bool h256_supported(const fastgrnn_desc& d, int direction) {
   if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
-  if (d.flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT)) return false;
+  if (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) return false;
+  // [B,F,T] input: 32-bit element offsets of a lane's frames
+  if ((d.flags & FASTGRNN_FLAG_X_BFT) && (double)d.B * F2 * d.T >= 4294967296.0) return false;
   // 32-bit byte offsets inside the d_pre workspace, its 16 sink rows included
   if (((double)d.T * d.B + 16.0) * H2 * 4.0 >= 4294967296.0) return false;
   if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;

@@ -1019,4 +1019,11 @@ int lowrank_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
 
+// fp32 [B,32,T] <-> [T,B,32] for the dense H = 256 layer's backward (kernels_h256.hip): its dW GEMM and d_x GEMM work on
+// time-major rows
+void bft_transpose_f32(int B, int T, const float* src, float* dst, bool to_time_major, hipStream_t s) {
+  if (to_time_major) hipLaunchKernelGGL((bft_transpose<float, true>), dim3(B), dim3(256), 0, s, B, T, src, dst);
+  else hipLaunchKernelGGL((bft_transpose<float, false>), dim3(B), dim3(256), 0, s, B, T, src, dst);
+}
+
 }  // namespace fastgrnn

@@ -765,12 +765,14 @@ def test_quant_tanh_update_on_the_matrix_pipe(gate, B):
     _check_grads(g, g_o, 5e-5, gate + "/quantTanh")
 
 
-@pytest.mark.parametrize("B,hs_batch_major", [(37, False), (64, False), (48, True)])
-def test_trainer_bft_input_layout_in_place(B, hs_batch_major):
+@pytest.mark.parametrize("B,hs_batch_major,H", [(37, False, 128), (64, False, 128), (48, True, 128),
+                                                 (37, False, 256), (64, False, 256)])
+def test_trainer_bft_input_layout_in_place(B, hs_batch_major, H):
     """FLAG_X_BFT: x / d_x in the data loader's [B,F,T] (trainClassifier.py:204 permutes it into
     a [T,B,F] view and the reference then copies it).  Same arithmetic: every output equals the time-major
-    run bit for bit."""
-    T, F, H = 23, 32, 128
+    run bit for bit.  H=128 and the reference's first layer H=256 (trainingConfig.py:12-15), which reads the
+    frames in place in the forward and takes a time-major copy in the backward's workspace."""
+    T, F = 23, 32
     SAVE_PREACT, BATCH_MAJOR, X_BFT = 4, 16, 128
     p = O.make_params(F, H, seed=6, randomize_scalars=True)
     P = _param_tensors(p)
@@ -798,14 +800,16 @@ def test_trainer_bft_input_layout_in_place(B, hs_batch_major):
     assert g_b[0].shape == (B, F, T) and torch.equal(g_t[0], g_b[0].permute(2, 0, 1))
     for a, b in zip(g_t[1:8], g_b[1:8]):
         assert torch.equal(a, b)
-    # not offered off the 8-wave dense kernels
-    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=X_BFT) != 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=fl) == 2
+    if H == 128:                                                   # not offered off the 8-wave dense kernels
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=X_BFT) != 2
 
 
-def test_module_takes_the_trainers_permuted_view():
+@pytest.mark.parametrize("H", [128, 256])
+def test_module_takes_the_trainers_permuted_view(H):
     """FastGRNNCUDA fed `audio.permute(2, 0, 1)` exactly as trainClassifier.py:204 does: same results and the
     same gradient on the loader's [B,F,T] tensor as with a contiguous copy, without making one."""
-    T, B, F, H = 29, 40, 32, 128
+    T, B, F = 29, 40, 32
     torch.manual_seed(8)
     m = FastGRNNCUDA(F, H, device=DEV)
     audio = torch.randn(B, F, T, device=DEV)

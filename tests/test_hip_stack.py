@@ -272,6 +272,36 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
     assert (np.abs(scores.cpu().numpy() - scores_o) / np.maximum(1.0, np.abs(scores_o))).max() <= 1e-5
 
 
+@pytest.mark.parametrize("want_dx", [False, True])
+def test_two_layer_model_reads_the_loaders_batch_in_place(stack_golden, want_dx):
+    """The trainer feeds `audio.permute(2, 0, 1)` of the loader's [B,F,T] batch (trainClassifier.py:204,299); the
+    reference's first layer (H=256) reads it in place (FASTGRNN_FLAG_X_BFT): same loss and gradients, bit for bit, as
+    with the contiguous copy the reference makes (rnn.py:910), with and without a gradient on the audio."""
+    g = stack_golden
+    T, B, F = g["x"].shape
+    assert fastgrnn_cuda.kernel_path(T, B, F, g["hidden"][0], direction=1,
+                                     flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_X_BFT) == 2
+    m = _build_model(g)
+    y = _t(g["labels"])
+    audio = _t(np.ascontiguousarray(g["x"].astype(np.float32).transpose(1, 2, 0)))       # [B,F,T]
+    res = []
+    for view in (True, False):
+        a = audio.clone().requires_grad_(want_dx)
+        xin = a.permute(2, 0, 1) if view else a.permute(2, 0, 1).contiguous()
+        for p_ in m.parameters():
+            p_.grad = None
+        m.init_hidden()
+        loss = m.loss(xin, y)
+        loss.backward()
+        res.append((loss.detach().clone(), a.grad.clone() if want_dx else None,
+                    {n: p_.grad.clone() for n, p_ in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and abs(float(res[0][0]) - float(g["loss"])) <= 1e-5
+    if want_dx:
+        assert res[0][1].shape == (B, F, T) and torch.equal(res[0][1], res[1][1])
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n
+
+
 @pytest.mark.parametrize("F,H", [(32, 256), (256, 128), (64, 128)])
 def test_input_gradient_is_optional_where_it_is_a_gemm_of_its_own(F, H):
     """fastgrnn_grads.d_x may be NULL on the H=256 and wide-input shapes (a model's first layer: its input is data):
