@@ -208,7 +208,12 @@ def main():
             step()
         torch.cuda.synchronize()
         est_ms = max(1e-3, (time.perf_counter() - t_spin) * 1e3 / 10)
-        for _ in range(int(args.spinup_ms / est_ms)):      # enqueued back to back: continuous load, no host gaps
+        n_spin = int(args.spinup_ms / est_ms)
+        if world > 1:                                      # every step holds a collective: all ranks run the SAME count
+            ns = torch.tensor([n_spin], dtype=torch.int64, device=dev)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+            n_spin = int(ns.item())
+        for _ in range(n_spin):                            # enqueued back to back: continuous load, no host gaps
             step()
     for _ in range(args.warmup):
         step()
