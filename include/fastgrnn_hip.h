@@ -93,10 +93,9 @@ typedef enum fastgrnn_nonlinearity {
 /* x and d_x are [B,F,T]: what the trainer's data loader delivers and permute(2,0,1)s into a [T,B,F] VIEW
  * (trainClassifier.py:204,299) that the reference then copies with .contiguous() (rnn.py:910).  Independent
  * of FASTGRNN_FLAG_BATCH_MAJOR (which then only governs hs, the saved tensor and grad_hs).  Kernel path 2:
- * dense H=128/F=32 (read and written in place; backward under FASTGRNN_FLAG_SAVE_PREACT), dense H=256/F=32 (the
- * forward reads it in place, the backward copies it time-major into its workspace for the dW / d_x GEMMs) and the
- * low-rank H=256/F=32 scans (through a time-major copy in the workspace, which is what the reference's
- * .contiguous() makes; backward under FASTGRNN_FLAG_SAVE_PREACT). */
+ * dense H=128/F=32 (read and written in place; backward under FASTGRNN_FLAG_SAVE_PREACT); dense H=256/F=32 and the
+ * low-rank H=256/F=32 scans through a time-major copy in the workspace (what the reference's .contiguous() makes,
+ * without the tensor it keeps alive for the backward; low-rank backward under FASTGRNN_FLAG_SAVE_PREACT). */
 #define FASTGRNN_FLAG_X_BFT 128u
 /* A/B only: keep the forward's state product U.h on three bf16 planes (6 MFMAs per K-step) instead of the
  * default fp16 two-plane operands with a per-wave power-of-two scale of U (3 MFMAs per K-step). */
@@ -163,8 +162,8 @@ const char *fastgrnn_hip_status_string(int status);
  *                                 sigmoid / relu / tanh gates, otherwise under FASTGRNN_FLAG_SAVE_PREACT.
  *   dense  H=128, F=64/128/256    (the reference's second layer) fp32; time- or batch-major; last-state flags.
  *   dense  H=256, F=32            (the reference's first layer) fp32; time-major hs / grad_hs; x time-major or the
- *                                 loader's [B,F,T] (FASTGRNN_FLAG_X_BFT: read in place by the forward, copied
- *                                 time-major into the backward's workspace for the dW / d_x GEMMs); last-state
+ *                                 loader's [B,F,T] (FASTGRNN_FLAG_X_BFT: transposed into the workspace by both
+ *                                 calls, 25 us at B = 4096; d_x comes back as [B,F,T]); last-state
  *                                 flags; gates sigmoid / relu / tanh with the reference's (z_s, h_prime_s)
  *                                 tensors, every gate under FASTGRNN_FLAG_SAVE_PREACT.
  *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags,
-    unsigned xs_b, unsigned xs_f, unsigned xs_t) {
+    float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags) {
   constexpr bool F16H = MODE == 1;
   if (MODE == 2 && flags[blockIdx.x] == 0u) return;  // (whole workgroup; no barrier has been passed)
   // One byte array carved per path (static LDS is the maximum over both):
@@ -183,10 +182,8 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     *reinterpret_cast<unsigned short*>(xpl + PLX2 + off) = s1;
     *reinterpret_cast<unsigned short*>(xpl + 2 * PLX2 + off) = s2;
   };
-  // this lane's value of frame t: xlane[t * xs_t].  x is [T,B,F] (xs_b = F, xs_f = 1, xs_t = B*F) or, under
-  // FASTGRNN_FLAG_X_BFT, the data loader's [B,F,T] read in place (xs_b = F*T, xs_f = T, xs_t = 1: trainClassifier.py:204)
-  const float* xlane = x + (size_t)xbc * xs_b + (size_t)xf * xs_f;
-  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * xs_t]; };
+  const float* xlane = x + (size_t)xbc * F2 + xf;          // this lane's value of frame t: xlane[t * B * F]
+  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * B * F2]; };
   const unsigned lane_hs = (unsigned)b * H2 + n0;
   auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
@@ -653,6 +650,8 @@ __global__ __launch_bounds__(1024) void reduce_h256_small(int nwg, const float* 
   }
 }
 
+static inline size_t h256_flag_bytes(const fastgrnn_desc& d) { return align256((size_t)((d.B + 15) / 16) * sizeof(unsigned)); }
+
 struct H256BwdWs { size_t part, dpre, tn, xtm, total; };
 H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
@@ -675,13 +674,17 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
   const bool ragged = (d.B % 16) != 0;
   const int aux = (d.flags & FASTGRNN_FLAG_HS_LAST) ? 3 : (zs == nullptr ? 0 : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? 2 : 1));
   unsigned* flags = reinterpret_cast<unsigned*>(ws);
-  const bool bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
-  const unsigned xs_b = bft ? (unsigned)(F2 * d.T) : (unsigned)F2, xs_f = bft ? (unsigned)d.T : 1u;
-  const unsigned xs_t = bft ? 1u : (unsigned)(d.B * F2);
+  // FASTGRNN_FLAG_X_BFT: the loader's [B,F,T] frames are transposed into the workspace first (25 us at B = 4096; a
+  // lane's frame-by-frame read of [B,F,T] in place touches 64 cache lines per wave load and cost the scan 120 us)
+  if (d.flags & FASTGRNN_FLAG_X_BFT) {
+    float* xtm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + h256_flag_bytes(d));
+    bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
+    x = xtm;
+  }
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
-                       (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags, xs_b, xs_f, xs_t);
+                       (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags);
   };
   // fp16 two-plane state product only for gates that keep z in [0,1] (see fwd_scan_split_w8); FWD_BF16X3: A/B
   constexpr bool BOUNDED = GATE == FASTGRNN_NL_SIGMOID || GATE == FASTGRNN_NL_QUANT_SIGM || GATE == FASTGRNN_NL_QUANT_SIGM4;
@@ -748,8 +751,6 @@ bool h256_shape(const fastgrnn_desc& d) {
 bool h256_supported(const fastgrnn_desc& d, int direction) {
   if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
   if (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) return false;
-  // [B,F,T] input: 32-bit element offsets of a lane's frames
-  if ((d.flags & FASTGRNN_FLAG_X_BFT) && (double)d.B * F2 * d.T >= 4294967296.0) return false;
   // 32-bit byte offsets inside the d_pre workspace, its 16 sink rows included
   if (((double)d.T * d.B + 16.0) * H2 * 4.0 >= 4294967296.0) return false;
   if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
@@ -759,7 +760,10 @@ bool h256_supported(const fastgrnn_desc& d, int direction) {
 
 size_t h256_backward_ws(const fastgrnn_desc& d) { return h256_bwd_layout(d).total; }
 // one word per workgroup: "my rows of h0 are outside the fp16 path's range" (fwd_scan_h256 MODE 1 -> MODE 2)
-size_t h256_forward_ws(const fastgrnn_desc& d) { return align256((size_t)((d.B + 15) / 16) * sizeof(unsigned)); }
+// + under FASTGRNN_FLAG_X_BFT the time-major copy of x
+size_t h256_forward_ws(const fastgrnn_desc& d) {
+  return h256_flag_bytes(d) + ((d.flags & FASTGRNN_FLAG_X_BFT) ? align256((size_t)d.T * d.B * F2 * 4) : 0);
+}
 
 int h256_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
                  void* cs, void* ws, hipStream_t s) {

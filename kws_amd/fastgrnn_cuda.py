@@ -132,7 +132,7 @@ _ws_cache = {}
 def _workspace(nbytes, device):
     if nbytes == 0:
         return None, C.c_void_p(None)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _raw_stream(device))
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -173,8 +173,19 @@ def _warn_fallback(plan, direction):
                   RuntimeWarning, stacklevel=4)
 
 
+def _raw_stream(device):
+    """The current stream's handle as an integer (the raw-stream query is one C call; building a torch.cuda.Stream
+    object for it cost ~5 us, twice per operator call)."""
+    idx = device.index
+    return _get_raw_stream(torch.cuda.current_device() if idx is None else idx)
+
+
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+    (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 def _stream(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return C.c_void_p(_raw_stream(device))
 
 
 def kernel_path(T, B, F, H, w_rank=0, u_rank=0, gate_nl=0, update_nl=2, dtype=torch.float32,

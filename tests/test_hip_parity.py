@@ -770,8 +770,8 @@ def test_quant_tanh_update_on_the_matrix_pipe(gate, B):
 def test_trainer_bft_input_layout_in_place(B, hs_batch_major, H):
     """FLAG_X_BFT: x / d_x in the data loader's [B,F,T] (trainClassifier.py:204 permutes it into
     a [T,B,F] view and the reference then copies it).  Same arithmetic: every output equals the time-major
-    run bit for bit.  H=128 and the reference's first layer H=256 (trainingConfig.py:12-15), which reads the
-    frames in place in the forward and takes a time-major copy in the backward's workspace."""
+    run bit for bit.  H=128 (in place) and the reference's first layer H=256 (trainingConfig.py:12-15), which
+    transposes the frames into its workspace in both calls."""
     T, F = 23, 32
     SAVE_PREACT, BATCH_MAJOR, X_BFT = 4, 16, 128
     p = O.make_params(F, H, seed=6, randomize_scalars=True)

@@ -275,7 +275,7 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
 @pytest.mark.parametrize("want_dx", [False, True])
 def test_two_layer_model_reads_the_loaders_batch_in_place(stack_golden, want_dx):
     """The trainer feeds `audio.permute(2, 0, 1)` of the loader's [B,F,T] batch (trainClassifier.py:204,299); the
-    reference's first layer (H=256) reads it in place (FASTGRNN_FLAG_X_BFT): same loss and gradients, bit for bit, as
+    reference's first layer (H=256) takes it as it is (FASTGRNN_FLAG_X_BFT, a workspace transpose): same loss and gradients, bit for bit, as
     with the contiguous copy the reference makes (rnn.py:910), with and without a gradient on the audio."""
     g = stack_golden
     T, B, F = g["x"].shape

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The reference's default model (two dense layers 32 -> 256 -> 128 + head) as a training step, for profiling:
     rocprofv3 --kernel-trace --stats -d <dir> -- python3 tools/stack_bench.py [steps] [B] [which]
-`which`: stack (default) | stack_bft (fed the loader's [B,F,T] batch as the trainer's permuted view: layer 1 reads
-it in place) | stack_copy (same view, copied with .contiguous() first as the reference does) | lowrank (BASELINE config 4) | l1 (H=256/F=32 layer alone) | l2 (H=128/F=256 alone)"""
+`which`: stack (default) | stack_bft (fed the loader's [B,F,T] batch as the trainer's permuted view: layer 1 takes
+it through FASTGRNN_FLAG_X_BFT) | stack_copy (same view, copied with .contiguous() first as the reference does) | lowrank (BASELINE config 4) | l1 (H=256/F=32 layer alone) | l2 (H=128/F=256 alone)"""
 import os
 import sys
 import time
