@@ -29,7 +29,12 @@ def step():
 for _ in range(300):
     step()
 torch.cuda.synchronize()
-for rep in range(3):
+from kws_amd import fastgrnn_cuda as _fc  # noqa: E402
+_fast = _fc._get_raw_stream
+_slow = lambda idx: torch.cuda.current_stream(idx).cuda_stream      # what the shim did before (A/B in one process)
+for rep in range(6):
+    _fc._get_raw_stream = _slow if rep % 2 else _fast
+    print("stream handle via %s:" % ("torch.cuda.current_stream()" if rep % 2 else "raw query"), end=" ")
     t0 = time.perf_counter()
     for _ in range(n):
         step()
@@ -37,6 +42,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print("B=%d: enqueue %.1f us/step, until done %.1f us/step" % (B, 1e6 * (t1 - t0) / n, 1e6 * (t2 - t0) / n))
+_fc._get_raw_stream = _fast
 # the same loop at one workgroup's worth of utterances: the floor of a step (99 serial frames per scan, twice, however
 # small the batch) or the host cost, whichever is larger
 xs, Gs = x[:, :16].contiguous(), G[:, :16].contiguous()
