@@ -155,6 +155,9 @@ def main():
                          "still raising its clock during the first tens of milliseconds of load")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1 only: capture the step in a HIP graph (kws_amd.GraphedStep) and time replays -- the same "
+                         "kernels with ~10 us of host work per step instead of 130-270 us; reported as host: hip_graph")
     ap.add_argument("--io", choices=["f32", "bf16"], default="f32",
                     help="sequence dtype: f32 (default; the reference's type) or bf16 frames/hidden states/grad_hs "
                          "with fp32 state, parameters and parameter gradients (BASELINE config 'bf16 with fp32 master grads')")
@@ -194,6 +197,13 @@ def main():
         hs.backward(G)                            # L = sum(hs*G): dL/dhs = G
         if bucket is not None:
             bucket.all_reduce_()
+
+    eager_step = step
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is an N=1 option (the gradient all-reduce stays outside the captured step)")
+        from kws_amd import GraphedStep
+        step = GraphedStep(eager_step)
 
     # Spin-up (untimed, reported as spinup_ms): a GPU that has been idle needs tens of milliseconds of load before its
     # clock settles -- with 5-10 warmup steps (2-4 ms) the timed region of a fresh box measured the ramp (0.41-0.47
@@ -243,6 +253,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing, fastgrnn_cuda._timing = samples, None
+    if args.graph:                  # events cannot be recorded inside a replay: sample the kernel durations on eager steps
+        torch.cuda.synchronize()
+        for i in range(8):
+            fastgrnn_cuda._timing = samples
+            eager_step()
+        torch.cuda.synchronize()
+        timing, fastgrnn_cuda._timing = samples, None
     # (beside the contract's single timed region: the median over 10 further blocks of the same K steps, so that a
     # 10-20 ms sample is not the only number -- reported as ms_per_step_median_of_blocks, never as `value`)
     blocks = []
@@ -288,7 +305,7 @@ def main():
             "dtype": ("bf16 sequences (x, hs, grad_hs, d_x); fp32 state, parameters, gradients (split-precision MFMA, fp32 accumulate)"
                       if args.io == "bf16" else
                       "f32 (split-precision MFMA: exact 3xbf16 planes, fp16 two-plane forward state product; fp32 accumulate)" if split else "f32"),
-            "data": "synthetic",
+            "data": "synthetic", "host": "hip_graph_replay" if args.graph else "eager",
             "config": {"workload": "FastGRNN dense fwd+bwd training step (FastGRNNCUDA module + autograd), T=99 F=32 "
                                    "H=128 B=%d per GPU, fp32 results, dense grad_hs; %s" % (
                                        B, "split-precision MFMA kernels, one saved [T,B,H] tensor" if split

@@ -10,6 +10,7 @@ from .head import KeywordHead, keyword_loss  # noqa: F401
 from .rnn import (FastGRNNCUDA, FastGRNNCUDACell, FastGRNNFunction,  # noqa: F401
                   FastGRNNUnrollFunction)
 from .model import RNNClassifierModel  # noqa: F401
+from .graph import GraphedStep  # noqa: F401
 
 __all__ = ["fastgrnn_cuda", "utils", "head", "FastGRNNCUDA", "FastGRNNCUDACell", "FastGRNNFunction",
-           "FastGRNNUnrollFunction", "KeywordHead", "keyword_loss", "RNNClassifierModel"]
+           "FastGRNNUnrollFunction", "KeywordHead", "keyword_loss", "RNNClassifierModel", "GraphedStep"]
