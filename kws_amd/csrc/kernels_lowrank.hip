@@ -229,39 +229,62 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
 // ------------------------------------------------------------------------------------------
 // Mirror of fwd_scan_lowrank_split.  Per step: EW on the VALU (z, c recomputed from the saved
 // pre-activation) -> d_pre; rank-space partial [U2|W2]^T d_pre over the wave's OWN units with the B
-// operand straight from registers; the four partials meet in LDS (one barrier); d_h = z*g + U1^T d_m_h
-// for the wave's own units and d_x = W1^T d_m_x.  d_pre[T,B,H] and d_m[T,B,32] go to the workspace:
-// the weight gradients (K = T*B) are contracted afterwards by split-K GEMMs (.cu:546-555 evaluated
-// factorised), because neither their accumulators nor the images they would need fit on chip beside
-// the factors.
+// operand straight from registers; the eight partials meet in LDS; d_h = z*g + U1^T d_m_h for the wave's own
+// units and d_x = W1^T d_m_x.
+// The factor gradients (.cu:546-555, evaluated factorised) are contracted INSIDE the scan since round 3 (they were
+// three split-K GEMMs over a d_pre[T,B,H] / d_m[T,B,32] round trip through HBM: 1.9 GB of the 2.8 GB the backward
+// moved).  Every product sums over the 16 utterances of the workgroup, which sit on the lanes, so both operands go
+// through the hardware-transposed LDS read -- but each wave only ever needs ITS OWN 32 units:
+//     d_u2|d_w2 [own unit][j] += d_pre_t[b][own unit] . m_t[b][j]         (2 x 2 tiles)
+//     d_u1^T    [own unit][j] += h_{t-1}[b][own unit] . d_m_h,t[b][j]     (2 tiles)
+//     d_w1^T    [f][j]        += x_t[b][f]            . d_m_x,t[b][j]     (2 tiles: waves 2 and 3, one each)
+// so the images of d_pre, h_prev and d_m are wave-PRIVATE (one 3 KB scratch per wave, used one after the other: LDS
+// instructions of a wave execute in order); the images of m_t and x_t -- the same for every wave -- are filled by
+// all 512 threads, one value each, in front of the step's first barrier.  K = 16 utterances is exactly one
+// v_mfma_f32_16x16x16_bf16 (lane group g holds k = 4g..4g+3 -- what ONE transposed read returns -- in two registers
+// per plane; same issue rate as the K = 32 form, tools/mfma_k16_probe.hip); the rank-space products d_h, d_x (K = 16
+// rank rows) use the same form.  Accumulators (28 registers) live for all T, per-workgroup slabs, one deterministic
+// reduce (reduce_lowrank_slabs).
 // Ranks below 16: the factors are zero-extended when they are loaded, as in the forward.  Row (t, b) of grad_hs / hs /
-// pre_s is t*rsT + b*rsB, of d_x t*xsT + b*xsB; the two workspace tensors are time-major.  glast: grad_hs is [B,H], the
-// gradient of the last state only (FASTGRNN_FLAG_GRAD_LAST).  BF: grad_hs, hs and d_x are bf16 (h0, pre_s fp32).
-constexpr int SLAB_LR = 576;   // floats per workgroup: d_bz[256] | d_bh[256] | (zeta, nu) sums, padded to 64
+// pre_s is t*rsT + b*rsB, of x / d_x t*xsT + b*xsB; the rank-space vector m_s is time-major.  glast: grad_hs is [B,H], the
+// gradient of the last state only (FASTGRNN_FLAG_GRAD_LAST).  BF: grad_hs, hs, x and d_x are bf16 (h0, pre_s, m_s fp32).
+// slab of one workgroup (floats): d_u2|d_w2 [256][32] | d_u1^T [256][16] | d_w1^T [32][16] | d_bz[256] | d_bh[256] | (zeta, nu)
+constexpr int SL_UW2 = 0, SL_U1T = 256 * 32, SL_W1T = SL_U1T + 256 * 16, SL_BZ = SL_W1T + 32 * 16, SL_ZN = SL_BZ + 512;
+constexpr int SLAB_LR = ((SL_ZN + 2 + 63) / 64) * 64;
 
-// RECOMP: pre_s is NULL and the pre-activation of step t is recomputed from the rank-space vector the forward saved,
-// pre = [U2|W2] . [m_h ; m_x] -- the forward's own second product (one K-step, six MFMA terms per row tile, same
-// operands in the same order: the same bits) with the [U2|W2] fragments parked in LDS.  Config 4 moves 3.8 GB per step
-// at 4.6 TB/s; the saved pre-activation is 0.83 GB of that (written by the forward, read here).
-template <int GATE, bool RAGGED, bool BF = false, bool RECOMP = false, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
+template <int GATE, bool RAGGED, bool BF = false>
+__global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     int Tn, int B, int rsT, int rsB, int xsT, int xsB, int rw, int ru, int glast,
-    const float* __restrict__ ghs, const float* __restrict__ hs, const float* __restrict__ pre_s,
-    const float* __restrict__ m_s,
+    const float* __restrict__ ghs, const float* __restrict__ x, const float* __restrict__ hs,
+    const float* __restrict__ pre_s, const float* __restrict__ m_s,
     const float* __restrict__ h0, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ u1, const float* __restrict__ u2,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
-    float* __restrict__ d_x, float* __restrict__ d_h0,
-    float* __restrict__ dpre_ws, float* __restrict__ dm_ws, float* __restrict__ part) {
-  // NW waves (8 = two per SIMD, 32 units each; 4 = the first shape): see fwd_scan_lowrank_split
-  constexpr int H = 256, F = 32, UPW = H / NW, NT = UPW / 16, KU = UPW / 32, UPL = UPW / 4, MROW = 36;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
+    float* __restrict__ d_x, float* __restrict__ d_h0, float* __restrict__ dx_sink, float* __restrict__ part) {
+  // 8 waves (two per SIMD), 32 units each (two 16-row tiles, one K-step over the own units): see fwd_scan_lowrank_split
+  constexpr int H = 256, F = 32, NW = 8, UPW = H / NW, NT = UPW / 16, UPL = UPW / 4, MROW = 36;
+  constexpr int IMG_PLANE = 1024;                    // one plane of an image: 16 utterances x 64 bytes
+  // rank-space partials of the eight waves and their sum: two barriers per step (every thread adds ONE value's eight
+  // partials, as in the forward; a wave that read all eight partials itself held 64 registers of them at once,
+  // which this kernel does not have), so neither buffer needs a second copy
+  __shared__ __attribute__((aligned(16))) float mp[NW][16][MROW];
+  __shared__ __attribute__((aligned(16))) float msum[16][MROW];
   __shared__ __attribute__((aligned(16))) float sbias[2][H];
   __shared__ float red[2 * NW];
-  __shared__ __attribute__((aligned(16))) u32x4 uw2l[RECOMP ? NW * NT * 3 * 64 : 1];   // [U2|W2] fragments, per wave
+  __shared__ __attribute__((aligned(16))) unsigned char wimg[NW][3 * IMG_PLANE];   // wave-private: d_pre_t, h_{t-1}, d_m_t
+  __shared__ __attribute__((aligned(16))) unsigned char simg[2][3 * IMG_PLANE];    // shared: m_t [b][32 j], x_t [b][32 f]
+  // The factor fragments are PARKED in LDS in fragment order and read back each step for the phase that uses them
+  // ([U2|W2]^T in front of the first barrier, U1^T and W1^T behind the second): registers are what this kernel is
+  // short of (28 accumulators + a step of operands in flight), LDS bandwidth is not.
+  __shared__ __attribute__((aligned(16))) u32x4 uw2tl[NW][2][3][64];
+  __shared__ __attribute__((aligned(16))) uint2 u1tl[NW][NT][3][64];
+  __shared__ __attribute__((aligned(16))) uint2 w1tl[2][3][64];
 
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, i = l & 15, g = l >> 4;
@@ -269,162 +292,172 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
   const bool valid = !RAGGED || b < B;
   const int bc = valid ? b : B - 1;
   const int n0 = wv * UPW + g * UPL;
-  const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
+  const bool xwave = (wv >> 1) == 1;                 // (wave-uniform) waves 2, 3: d_w1, feature tile wv & 1
+  // (wave-uniform: kept in scalar registers)
+  const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fsigmoid(zeta[0]))));
+  const float sn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fsigmoid(nu[0]))));
   if (tid < H) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
 
-  // ---- resident A operands -----------------------------------------------------------------
-  // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units: tile 0 rows = U2 columns, tile 1 = W2 columns
-  Frag3 UW2Tf[2][KU];
+  // ---- A operands, parked ---------------------------------------------------------------------
+  // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units (K = 32): tile 0 rows = U2 columns, tile 1 = W2 columns
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     const float* src = tl == 0 ? u2 : w2;
     const int rk = tl == 0 ? ru : rw;
     const int ic = i < rk ? i : 0;
+    f32x4 lo, hi;
 #pragma unroll
-    for (int v = 0; v < KU; ++v) {
-      f32x4 lo, hi;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = i < rk ? src[(size_t)(n0 + 8 * v + j) * rk + ic] : 0.f;
-        hi[j] = i < rk ? src[(size_t)(n0 + 8 * v + 4 + j) * rk + ic] : 0.f;
-      }
-      UW2Tf[tl][v] = split3(lo, hi);
+    for (int j = 0; j < 4; ++j) {
+      lo[j] = i < rk ? src[(size_t)(n0 + j) * rk + ic] : 0.f;
+      hi[j] = i < rk ? src[(size_t)(n0 + 4 + j) * rk + ic] : 0.f;
     }
+    const Frag3 f = split3(lo, hi);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) uw2tl[wv][tl][pl][l] = f.p[pl];
   }
-  // d_h[k][b] = z*g + sum_j U1[j][k] d_m_h[j][b]: rows = own units, K = [d_m_h rows 8g.. | nothing]
-  Frag3 U1Tf[NT];
+  auto load_uw2t = [&](Frag3 (&f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f[tl].p[pl] = uw2tl[wv][tl][pl][l];
+  };
+  // d_h[k][b] = z*g + sum_j U1[j][k] d_m_h[j][b]: rows = own units (row 4c + r of tile mt = unit 8c + 4mt + r of the
+  // wave, the unit lane (b, c) holds as element r of tile mt), K = the 16 rank rows: lane group g holds j = 4g..4g+3
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {
     const int kA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
-    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-    if (g < 2) {
+    f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = 8 * g + j < ru ? u1[(size_t)(8 * g + j) * H + kA] : 0.f;
-        hi[j] = 8 * g + 4 + j < ru ? u1[(size_t)(8 * g + 4 + j) * H + kA] : 0.f;
-      }
-    }
-    U1Tf[mt] = split3(lo, hi);
+    for (int j = 0; j < 4; ++j) v[j] = 4 * g + j < ru ? u1[(size_t)(4 * g + j) * H + kA] : 0.f;
+    uint2 q0, q1, q2;
+    split_quad(v, q0, q1, q2);
+    u1tl[wv][mt][0][l] = q0; u1tl[wv][mt][1][l] = q1; u1tl[wv][mt][2][l] = q2;
   }
-  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv&1 (stored by waves 0,1), K = [nothing | d_m_x rows 8(g-2)..]
-  Frag3 W1Tf;
-  {
-    const int f = (wv & 1) * 16 + i;
-    f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-    if (g >= 2) {
+  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv (waves 0, 1), K = the 16 rank rows
+  if (wv < 2) {
+    const int f = wv * 16 + i;
+    f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = 8 * (g - 2) + j < rw ? w1[(size_t)(8 * (g - 2) + j) * F + f] : 0.f;
-        hi[j] = 8 * (g - 2) + 4 + j < rw ? w1[(size_t)(8 * (g - 2) + 4 + j) * F + f] : 0.f;
-      }
-    }
-    W1Tf = split3(lo, hi);
+    for (int j = 0; j < 4; ++j) v[j] = 4 * g + j < rw ? w1[(size_t)(4 * g + j) * F + f] : 0.f;
+    uint2 q0, q1, q2;
+    split_quad(v, q0, q1, q2);
+    w1tl[wv][0][l] = q0; w1tl[wv][1][l] = q1; w1tl[wv][2][l] = q2;
   }
-
-  if (RECOMP) {                                    // rows = own units; K = [m_h rows 8g.. | m_x rows 8(g-2)..]: as the forward
+  auto load_u1t = [&](Half3 (&f)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      const int nA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
-      const int rk = g < 2 ? ru : rw, j0 = g < 2 ? 8 * g : 8 * (g - 2);
-      const float* pf = (g < 2 ? u2 : w2) + (size_t)nA * rk;
-      f32x4 lo, hi;
+    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo[j] = j0 + j < rk ? pf[j0 + j] : 0.f;
-        hi[j] = j0 + 4 + j < rk ? pf[j0 + 4 + j] : 0.f;
-      }
-      const Frag3 f = split3(lo, hi);
+      for (int pl = 0; pl < 3; ++pl) f[mt].p[pl] = __builtin_bit_cast(s16x4, u1tl[wv][mt][pl][l]);
+  };
+  auto load_w1t = [&](Half3& f) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) uw2l[((wv * NT + mt) * 3 + pl) * 64 + l] = f.p[pl];
-    }
-  }
+    for (int pl = 0; pl < 3; ++pl) f.p[pl] = __builtin_bit_cast(s16x4, w1tl[wv & 1][pl][l]);
+  };
 
   f32x4 sbz[NT], sbh[NT], dh[NT];
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) { sbz[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; sbh[mt] = sbz[mt]; dh[mt] = sbz[mt]; }
   float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;     // d_zeta / d_nu partial sums, compensated
+  // factor-gradient accumulators, resident for all T: [row tile of own units][U2 | W2 columns], d_u1^T, d_w1^T
+  f32x4 accUW[NT][2], accU1[NT], accW1;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) { accUW[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accUW[a][1] = accUW[a][0]; accU1[a] = accUW[a][0]; }
+  accW1 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // grad_hs, pre-activation (RECOMP: a0[0], a0[1] carry the 8 rank-space values of this lane's K rows), h_prev
-  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; };
-  static_assert(!RECOMP || NT == 2, "the recomputation parks the rank-space fragment in a0[0..1]");
-  // Addresses are a wave-uniform step base (scalar registers) + a 32-bit lane offset: one VGPR per stream instead
-  // of a 64-bit pointer pair each (the host rejects B*H*4 >= 2^31 for this path).
-  const unsigned lane_h = (unsigned)bc * rsB * H + n0, lane_0 = (unsigned)bc * H + n0;
-  // stores: rows of the two workspace tensors advance by B per step for the lanes of the batch and not at all for
-  // the others, whose rows are the 16 sink rows behind row T*B; d_x likewise, its sink behind d_m's
-  const unsigned sk_step = valid ? (unsigned)B : 0u;
-  const unsigned sk_row = valid ? (unsigned)b : (unsigned)Tn * (unsigned)B + i;
-  const unsigned dp_off = (sk_row * H + n0) * 4u, dm_off = (sk_row * 32 + 8 * g) * 4u;
-  constexpr unsigned XSZ = BF ? 2u : 4u;
-  char* const dx_base = valid ? reinterpret_cast<char*>(d_x) + ((size_t)b * xsB * F + (wv & 1) * 16 + 4 * g) * XSZ
-                              : reinterpret_cast<char*>(dm_ws) + (((size_t)Tn * B + 16) * 32 + i * 32 + (wv & 1) * 16 + 4 * g) * 4u;
-  const unsigned dx_step = valid ? (unsigned)xsT * F * XSZ : 0u;
-  auto ld4s = [&](const float* base, unsigned e) __attribute__((always_inline)) -> f32x4 {   // 4 sequence elements
+  // ---- plane images ---------------------------------------------------------------------------
+  // natural order [utterance][32 columns] bf16, 64-byte rows, one plane per KB.  Private image: a lane writes its 8
+  // values of utterance i (16 bytes per plane) and reads back, transposed, utterances 4g..4g+3 of column 16*tile + i.
+  unsigned char* const my_img = &wimg[wv][0];
+  const unsigned wr_off = (unsigned)(i * 64 + g * 16);
+  const unsigned tr_lane = (unsigned)((4 * g + (i >> 2)) * 64 + (i & 3) * 8);
+  const unsigned tr_off = (unsigned)(size_t)my_img + tr_lane;
+  const unsigned trs_off = (unsigned)(size_t)&simg[0][0] + tr_lane;
+  auto img_fence = []() __attribute__((always_inline)) { asm volatile("" ::: "memory"); };   // (compiler ordering only)
+  auto put_img = [&](const Frag3& f) __attribute__((always_inline)) {
+    img_fence();
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(my_img + pl * IMG_PLANE + wr_off) = f.p[pl];
+    img_fence();
+  };
+  auto tr_half_at = [&](unsigned addr, Half3& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      f.p[pl] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((size_t)(addr + pl * IMG_PLANE)));
+  };
+  auto tr_half = [&](int tile, Half3& f) __attribute__((always_inline)) { tr_half_at(tr_off + tile * 32, f); };
+  // Shared images: thread (su, sc) = (tid >> 5, tid & 31) owns value sc of utterance su of m_t and of x_t
+  const int su = tid >> 5, sc = tid & 31;
+  const int sb = blockIdx.x * 16 + su, sbc = (!RAGGED || sb < B) ? sb : B - 1;
+  unsigned char* const my_s = &simg[0][0] + su * 64 + sc * 2;
+  auto fresh_lane = [&]() __attribute__((always_inline)) { unsigned v = (unsigned)l; asm volatile("" : "+v"(v)); return v; };
+
+  // grad_hs, pre-activation, h_prev of the lane's 8 units; one value of the step's rank-space vector and frame
+  struct EwOps { f32x4 g[NT], a0[NT], h[NT]; float m1, x1; };
+  // Addresses: buffer loads -- a resource descriptor (four scalar registers per tensor), a wave-uniform step offset in
+  // a scalar register and ONE loop-invariant 32-bit byte offset per lane, shared by every stream with the same row
+  // geometry.  (Left to itself the compiler keeps a 64-bit pointer pair per stream in vector registers and advances
+  // each per step: sixteen registers this kernel does not have.  The host keeps whole tensors below 2^32 bytes.)
+  constexpr unsigned ESZ = BF ? 2u : 4u;             // bytes per sequence element (grad_hs, hs, x, d_x)
+  auto rsrc_of = [](const void* p) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_g = rsrc_of(ghs), r_hs = rsrc_of(hs), r_pre = rsrc_of(pre_s), r_m = rsrc_of(m_s),
+                               r_x = rsrc_of(x), r_h0 = rsrc_of(h0);
+  const unsigned lane_h = (unsigned)bc * rsB * H + n0, lane_0 = (unsigned)bc * H + n0;   // elements
+  const unsigned lane_g = glast ? lane_0 : lane_h;
+  const unsigned lane_m1 = ((unsigned)sbc * 32 + sc) * 4u, lane_x1 = ((unsigned)sbc * xsB * F + sc) * ESZ;   // bytes
+  // d_x: every lane stores, lanes beyond a ragged batch into 16 sink rows of the workspace (step stride 0)
+  char* const dx_base = valid ? reinterpret_cast<char*>(d_x) + ((size_t)b * xsB * F + (wv & 1) * 16 + 4 * g) * ESZ
+                              : reinterpret_cast<char*>(dx_sink) + (i * 32 + (wv & 1) * 16 + 4 * g) * 4u;
+  const unsigned dx_step = valid ? (unsigned)xsT * F * ESZ : 0u;
+  auto bld4 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) __attribute__((always_inline)) -> f32x4 {   // 4 floats
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  };
+  auto bld4s = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) __attribute__((always_inline)) -> f32x4 {   // 4 sequence elements
     if (BF) {
-      const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e);
-      return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
-                   __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+      const uint2 q = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+      return f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                   __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
     }
-    return ld4(base + e);
+    return bld4(r, voff, soff);
   };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t step = (size_t)t * rsT * H;                                 // uniform; in elements
-    const float* pt = pre_s + step;
-    // sequence tensors are addressed in ELEMENTS from their typed base (bf16: half the bytes)
-    const size_t gstep = glast ? 0 : step, hstep = step - (size_t)rsT * H;
-    const unsigned lane_g = glast ? lane_0 : lane_h;
+    // wave-uniform offsets of step t's rows (scalar registers)
+    const unsigned step = (unsigned)t * (unsigned)rsT * H;                   // elements
+    const unsigned gstep = glast ? 0u : step, hstep = step - (unsigned)rsT * H;
     const bool gzero = (RAGGED && !valid) || (glast && t != Tn - 1);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
       // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero, so gg,
-      // d_pre and every sum they enter stay exactly zero for them; see bwd_scan_split_w8)
-      e.g[mt] = gzero ? f32x4{0.f, 0.f, 0.f, 0.f}
-                      : ld4s(BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(ghs) + gstep) : ghs + gstep,
-                             lane_g + 4 * mt);
-      if (RECOMP) e.a0[mt] = ld4(m_s + ((size_t)t * B + bc) * 32 + 8 * g + 4 * mt);   // rows 8g.. of [m_h ; m_x], time-major
-      else e.a0[mt] = ld4(pt + lane_h + 4 * mt);
-      if (t == 0) e.h[mt] = ld4(h0 + lane_0 + 4 * mt);                       // .cu:478-481
-      else e.h[mt] = ld4s(BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(hs) + hstep) : hs + hstep,
-                          lane_h + 4 * mt);
+      // d_pre and every sum or product they enter stay exactly zero for them; see bwd_scan_split_w8)
+      const f32x4 gv = bld4s(r_g, lane_g * ESZ, (gstep + 4 * mt) * ESZ);
+      e.g[mt] = gzero ? f32x4{0.f, 0.f, 0.f, 0.f} : gv;
+      e.a0[mt] = bld4(r_pre, lane_h * 4u, (step + 4 * mt) * 4u);
+      // h_prev of step 0 is h0 (.cu:478-481).  fp32: one load whose descriptor and offsets are selected in scalar
+      // registers (no branch); bf16 sequences: h0 is fp32, a different load
+      if (BF) {
+        if (t == 0) e.h[mt] = bld4(r_h0, lane_0 * 4u, 16u * mt);
+        else e.h[mt] = bld4s(r_hs, lane_h * ESZ, (hstep + 4 * mt) * ESZ);
+      } else {
+        e.h[mt] = bld4(t == 0 ? r_h0 : r_hs, (t == 0 ? lane_0 : lane_h) * 4u, (t == 0 ? 4u * mt : hstep + 4 * mt) * 4u);
+      }
     }
+    e.m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_m, (int)lane_m1, (int)((unsigned)t * (unsigned)B * 128u), 0));
+    const unsigned xstep = (unsigned)t * (unsigned)xsT * F * ESZ;
+    if (BF) e.x1 = bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r_x, (int)lane_x1, (int)xstep, 0));
+    else e.x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, (int)lane_x1, (int)xstep, 0));
   };
 
-  // RECOMP: e.a0 arrives holding this lane's 8 rank-space values and leaves holding the pre-activation of the own units.
-  // Two parts, because the fragments must be in registers of their own BEFORE any MFMA that is still in flight when
-  // they are requested (operand rule): recomp_prep reads them (and splits the rank-space values), recomp_issue runs
-  // the products and ends with their completion read.
-  struct Recomp { Frag3 Uf[NT], mBf; };
-  auto recomp_prep = [&](const EwOps& e, Recomp& rc) __attribute__((always_inline)) {
-    rc.mBf = split3(e.a0[0], e.a0[1]);
+  // transposed operands of the step's d_u1^T / d_w1^T products.  They are loop-carried on purpose: those products are
+  // the step's youngest MFMAs and nothing of the recurrence depends on them, so their completion read sits BEHIND the
+  // next step's element-wise work, and until then these registers stay allocated (operand rule)
+  Half3 Ahp[NT], Bdm, Ax, Bdmx;
+  {
+    const s16x4 z4 = s16x4{0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rc.Uf[mt].p[pl] = uw2l[((wv * NT + mt) * 3 + pl) * 64 + l];
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto recomp_issue = [&](EwOps& e, const Recomp& rc) __attribute__((always_inline)) {
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) e.a0[mt] = mfma6(rc.Uf[mt], rc.mBf, f32x4{0.f, 0.f, 0.f, 0.f});  // rnn.py:281,287,289
-    __builtin_amdgcn_sched_barrier(0);
-    // completion read HERE: the next step's first instructions are LDS reads (the biases) that the compiler would
-    // otherwise land in the fragments' dead registers right behind the MFMAs (operand rule; the scanner found it)
-    float touch = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) touch += e.a0[mt][0];
-    if (touch == 1.2345678e38f) red[1] = 1.f;
-    __builtin_amdgcn_sched_barrier(0);
-  };
+    for (int pl = 0; pl < 3; ++pl) { Ahp[0].p[pl] = z4; Ahp[1].p[pl] = z4; Bdm.p[pl] = z4; Ax.p[pl] = z4; Bdmx.p[pl] = z4; }
+  }
   auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const int cur = t & 1;
-    {
-      // dh read = the previous step's MFMAs have retired: the requests below may land in registers they read
-      // (operand rule)
-      float touch = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
-      if (touch == 1.2345678e38f) red[0] = 1.f;
-      __builtin_amdgcn_sched_barrier(0);
-    }
     // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
     f32x4 dpv[NT];
     float sz8 = 0.f, sn8 = 0.f;
@@ -447,83 +480,178 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       }
     }
     kahan_add(pz, pz_c, sz8); kahan_add(pn, pn_c, sn8);
-    // EW(t) has consumed the operand set (and read dh: the previous step's MFMAs have retired): refill it for t-1
+    {
+      // completion read of the PREVIOUS step's youngest products (see Ahp): from here on their operand registers are free
+      float tie = accU1[NT - 1][0];
+      asm volatile("" : "+v"(tie)
+                   : "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
+                     "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
+                     "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
+      if (tie == 1.2345678e38f) red[0] = 1.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    SPLIT_STAMP(0)
+    // ---- planes of d_pre_t (B operand of the rank-space partial as they are; transposed, the A operand of the
+    //      d_u2|d_w2 products) and of h_{t-1} through the private image; one value each of m_t and x_t into the shared ones
+    const Frag3 dfr = split3(dpv[0], dpv[1]);
+    Half3 Adp[NT];
+    put_img(dfr);
+    tr_half(0, Adp[0]); tr_half(1, Adp[1]);
+    put_img(split3(e.h[0], e.h[1]));                 // (stays in the image until the products behind the barriers want it)
+    {
+      unsigned short s0, s1, s2;
+      split_one(e.m1, s0, s1, s2);
+      *reinterpret_cast<unsigned short*>(my_s) = s0;
+      *reinterpret_cast<unsigned short*>(my_s + IMG_PLANE) = s1;
+      *reinterpret_cast<unsigned short*>(my_s + 2 * IMG_PLANE) = s2;
+      split_one(e.x1, s0, s1, s2);
+      *reinterpret_cast<unsigned short*>(my_s + 3 * IMG_PLANE) = s0;
+      *reinterpret_cast<unsigned short*>(my_s + 4 * IMG_PLANE) = s1;
+      *reinterpret_cast<unsigned short*>(my_s + 5 * IMG_PLANE) = s2;
+    }
+    Frag3 UW2Tf[2];
+    load_uw2t(UW2Tf);
+    // EW(t) has consumed the operand set (and the previous step's MFMAs have retired): refill it for t-1
     __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
     if (t > 0) load_ew(t - 1, e);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      // every lane stores, without a branch: lanes beyond a ragged batch write to sink rows behind the T*B rows
-      // (step stride 0) -- no exec-masked block around memory instructions in the steady state
-      char* o = reinterpret_cast<char*>(dpre_ws) + (size_t)t * sk_step * (H * 4u) + dp_off;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt) *reinterpret_cast<f32x4*>(o + 16 * mt) = dpv[mt];
-    }
-    // ---- rank-space partial over own units: B operand = this lane's two fragments of d_pre ----
-    Frag3 dfr[KU];
-#pragma unroll
-    for (int v = 0; v < KU; ++v) dfr[v] = split3(dpv[2 * v], dpv[2 * v + 1]);
+    SPLIT_STAMP(2)
+    // ---- rank-space partial over own units: B operand = this lane's fragment of d_pre ----
     // big and small terms in accumulators of their own, as in the dense scans (mfma6_hl: inside one MFMA the
     // addends are chopped at the largest one, a one-signed loss that showed in d_zeta / d_nu at B = 4096)
     f32x4 mh = f32x4{0.f, 0.f, 0.f, 0.f}, mx = mh, mhl = mh, mxl = mh;
-#pragma unroll
-    for (int v = 0; v < KU; ++v) mfma6_hl(UW2Tf[0][v], dfr[v], mh, mhl);
-#pragma unroll
-    for (int v = 0; v < KU; ++v) mfma6_hl(UW2Tf[1][v], dfr[v], mx, mxl);
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh + mhl;
-    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx + mxl;
+    mfma6_hl(UW2Tf[0], dfr, mh, mhl);
+    mfma6_hl(UW2Tf[1], dfr, mx, mxl);
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<f32x4*>(&mp[wv][i][4 * g]) = mh + mhl;
+    *reinterpret_cast<f32x4*>(&mp[wv][i][16 + 4 * g]) = mx + mxl;
+    SPLIT_STAMP(3)
     lds_barrier();
-    f32x4 mlo = f32x4{0.f, 0.f, 0.f, 0.f}, mhi = mlo;
-    // (the forward's two-stage sum was tried here too: 1 % at most, and its extra registers made the kernel spill)
+    {
+      // 512 threads = 16 utterances x 32 values: each adds one value's eight partials, in wave order
+      const int u = tid & 15, j = tid >> 4;
+      float sj = 0.f;
 #pragma unroll
-    for (int w2i = 0; w2i < NW; ++w2i) {
-      mlo += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g]);
-      mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
+      for (int w2i = 0; w2i < NW; ++w2i) sj += mp[w2i][u][j];
+      msum[u][j] = sj;
     }
-    if (wv == 0) {                                   // (wave-uniform) [d_m_h | d_m_x] of this step for the weight-gradient GEMMs
-      char* mo = reinterpret_cast<char*>(dm_ws) + (size_t)t * sk_step * (32 * 4u) + dm_off;
-      *reinterpret_cast<f32x4*>(mo) = mlo; *reinterpret_cast<f32x4*>(mo + 16) = mhi;
+    // d_u2 | d_w2 += d_pre_t^T . [m_h | m_x]_t  (.cu:546-555): between the barriers, where a wave otherwise waits
+    Half3 Bm[2];
+    {
+      tr_half_at(trs_off, Bm[0]); tr_half_at(trs_off + 32, Bm[1]);
+      if (xwave) tr_half_at(trs_off + 3 * IMG_PLANE + (wv & 1) * 32, Ax);   // (x_t's image is rewritten behind the next barrier)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) accUW[a][c] = mfma6_k16(Adp[a], Bm[c], accUW[a][c]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const Frag3 mB = split3(mlo, mhi);
-    Recomp rc;
-    if (RECOMP && t > 0) recomp_prep(e, rc);         // (fragments of the NEXT step's pre-activation: requested before the products below)
+    lds_barrier();
+    SPLIT_STAMP(4)
+    // ---- [d_m_h | d_m_x]_t of utterance i: rank rows 4g..4g+3 of either half ------------------------------
+    const f32x4 dmh = *reinterpret_cast<const f32x4*>(&msum[i][4 * g]);
+    const f32x4 dmx = *reinterpret_cast<const f32x4*>(&msum[i][16 + 4 * g]);
+    uint2 h0q, h1q, h2q, x0q, x1q, x2q;
+    split_quad(dmh, h0q, h1q, h2q);
+    split_quad(dmx, x0q, x1q, x2q);
+    Half3 mBh, mBx;
+    mBh.p[0] = __builtin_bit_cast(s16x4, h0q); mBh.p[1] = __builtin_bit_cast(s16x4, h1q); mBh.p[2] = __builtin_bit_cast(s16x4, h2q);
+    mBx.p[0] = __builtin_bit_cast(s16x4, x0q); mBx.p[1] = __builtin_bit_cast(s16x4, x1q); mBx.p[2] = __builtin_bit_cast(s16x4, x2q);
     // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
-    f32x4 dlo[NT];
+    {
+      Half3 U1Tf[NT], W1Tf;
+      load_u1t(U1Tf);
+      if (wv < 2) load_w1t(W1Tf);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 dlo[NT];
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) { dlo[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; mfma6_hl(U1Tf[mt], mB, dh[mt], dlo[mt]); }
-    if (wv < 2) {                                    // (wave-uniform) feature tile wv
-      f32x4 dxv = f32x4{0.f, 0.f, 0.f, 0.f}, dxl = dxv;
-      mfma6_hl(W1Tf, mB, dxv, dxl);
-      dxv += dxl;
-      {                                              // lanes beyond a ragged batch: the sink behind d_m (dx_base)
-        char* o = dx_base + (size_t)t * dx_step;
-        if (BF) st4_bf16(o, dxv); else *reinterpret_cast<f32x4*>(o) = dxv;
+      for (int mt = 0; mt < NT; ++mt) { dlo[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; mfma6_hl_k16(U1Tf[mt], mBh, dh[mt], dlo[mt]); }
+      if (wv < 2) {                                  // (wave-uniform) feature tile wv
+        f32x4 dxv = f32x4{0.f, 0.f, 0.f, 0.f}, dxl = dxv;
+        mfma6_hl_k16(W1Tf, mBx, dxv, dxl);
+        dxv += dxl;
+        {                                            // lanes beyond a ragged batch: the sink rows (dx_base)
+          char* o = dx_base + (size_t)t * dx_step;
+          if (BF) st4_bf16(o, dxv); else *reinterpret_cast<f32x4*>(o) = dxv;
+        }
       }
-    }
-    // RECOMP: the next step's pre-activation now, behind this step's last products in the matrix pipe (at the top of
-    // the next step it is a dependent phase of ~350 cycles in front of EW: +34 us per launch, measured)
-    if (RECOMP && t > 0) recomp_issue(e, rc);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
+      for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
+      // (this sum read the youngest of the products above: their operand registers are free for the reads below --
+      // and so are, only now, those of the d_u2|d_w2 products issued between the barriers, which nothing else has
+      // waited for: kept allocated up to here)
+      asm volatile("" : "+v"(dh[0]), "+v"(dh[1])
+                   : "v"(Adp[0].p[0]), "v"(Adp[0].p[1]), "v"(Adp[0].p[2]), "v"(Adp[1].p[0]), "v"(Adp[1].p[1]), "v"(Adp[1].p[2]),
+                     "v"(Bm[0].p[0]), "v"(Bm[0].p[1]), "v"(Bm[0].p[2]), "v"(Bm[1].p[0]), "v"(Bm[1].p[1]), "v"(Bm[1].p[2]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    SPLIT_STAMP(5)
+    // ---- h_{t-1} comes back out of the private image, transposed; then the planes of [d_m_h | d_m_x]_t go through it:
+    //      the B operand of d_u1^T (columns 0..15) and d_w1^T (16..31)
+    tr_half(0, Ahp[0]); tr_half(1, Ahp[1]);          // (in front of the image's next use: LDS runs a wave's instructions in order)
+    img_fence();
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + g * 8) = mBh.p[pl];
+      *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + 32 + g * 8) = mBx.p[pl];
+    }
+    img_fence();
+    tr_half(0, Bdm);
+    if (xwave) tr_half(1, Bdmx);
+    __builtin_amdgcn_sched_barrier(0);
+    // d_w1^T += x_t^T . d_m_x,t (waves 2, 3), then d_u1^T += h_{t-1}^T . d_m_h,t -- the step's youngest products in
+    // EVERY wave: one read of accU1 proves the whole step has retired
+    if (xwave) accW1 = mfma6_k16(Ax, Bdmx, accW1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < NT; ++a) accU1[a] = mfma6_k16(Ahp[a], Bdm, accU1[a]);
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(6)
   };
 
   EwOps ea;                                          // ONE operand set, refilled right behind its use (see step)
-  __syncthreads();                                   // sbias
+  __syncthreads();                                   // sbias, parked fragments
   load_ew(Tn - 1, ea);
-  if (RECOMP) { Recomp rc0; recomp_prep(ea, rc0); recomp_issue(ea, rc0); }
   for (int t = Tn - 1; t >= 0; --t) step(t, ea);
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && (tid & 63) == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
+#endif
   {
-    // the last step's MFMAs have retired before anything below (stores masked by `valid`, the reductions' LDS
-    // traffic) may reuse their operand registers: an unconditional read of every d_h accumulator
-    float touch = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) touch += dh[mt][0];
-    if (touch == 1.2345678e38f) red[0] = 1.f;
+    // the last step's MFMAs have retired before anything below may reuse their operand registers
+    float tie = accU1[NT - 1][0];
+    asm volatile("" : "+v"(tie)
+                 : "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
+                   "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
+                   "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
+    if (tie == 1.2345678e38f) red[0] = 1.f;
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- flush ---------------------------------------------------------------------------------
-  if (valid) {
+  // (lane geometry recomputed from the lane id: nothing of it has to stay in a register across the scan)
+  const unsigned lf = fresh_lane();
+  const int fi = (int)(lf & 15u), fg = (int)(lf >> 4);
+  const int fb = blockIdx.x * 16 + fi, fn0 = wv * UPW + fg * UPL;
+  if (!RAGGED || fb < B) {
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) st4(d_h0 + (size_t)b * H + n0 + 4 * mt, dh[mt]);
+    for (int mt = 0; mt < NT; ++mt) st4(d_h0 + (size_t)fb * H + fn0 + 4 * mt, dh[mt]);
+  }
+  float* const ps = part + (size_t)blockIdx.x * SLAB_LR;
+  // D row 4g + r of tile a = own unit 8g + 4a + r (see the parked U1^T fragments); column i = rank index j
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wv * UPW + 16 * a + 4 * fg + r;
+      ps[SL_UW2 + n * 32 + fi] = accUW[a][0][r];
+      ps[SL_UW2 + n * 32 + 16 + fi] = accUW[a][1][r];
+      ps[SL_U1T + n * 16 + fi] = accU1[a][r];
+    }
+  if (xwave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[SL_W1T + ((wv & 1) * 16 + 4 * fg + r) * 16 + fi] = accW1[r];
   }
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt)
@@ -532,237 +660,38 @@ __global__ __launch_bounds__(NW * 64) void bwd_scan_lowrank_split(
       float a = sbz[mt][r], c = sbh[mt][r];
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); c += __shfl_xor(c, m); }
-      if (i == 0) {
-        float* pb = part + (size_t)blockIdx.x * SLAB_LR;
-        pb[n0 + 4 * mt + r] = a;
-        pb[H + n0 + 4 * mt + r] = c;
+      if (fi == 0) {
+        ps[SL_BZ + fn0 + 4 * mt + r] = a;
+        ps[SL_BZ + H + fn0 + 4 * mt + r] = c;
       }
     }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { pz += __shfl_xor(pz, m); pn += __shfl_xor(pn, m); }
-  if (l == 0) { red[wv] = pz; red[NW + wv] = pn; }
+  if ((lf & 63u) == 0) { red[wv] = pz; red[NW + wv] = pn; }
   __syncthreads();
   if (tid == 0) {
-    float* pzn = part + (size_t)blockIdx.x * SLAB_LR + 2 * H;
     float a = 0.f, c = 0.f;
 #pragma unroll
     for (int w2i = 0; w2i < NW; ++w2i) { a += red[w2i]; c += red[NW + w2i]; }
-    pzn[0] = a; pzn[1] = c;
+    ps[SL_ZN] = a; ps[SL_ZN + 1] = c;
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// C[M,N] = A[:, :M]^T . B[:, :N] over R rows (R = T*B, huge; M, N small): split-precision, matrix pipe
-// ------------------------------------------------------------------------------------------
-// The weight gradients of the low-rank backward (.cu:546-555, factorised).  Workgroup = 4 waves = one
-// chunk of TN_CHUNK rows, staged 32 rows at a time: global fp32 -> three exact bf16 planes in LDS in
-// natural [row][column] order -> hardware-transposed fragment reads (K = rows) -> 6-term MFMAs into
-// register accumulators.  Each workgroup leaves its partial C in the workspace; tn_reduce sums them
-// in a fixed order.  MT x NT = 16x16 tiles of C; wave w owns tiles w, w+4, ...
-// MAPB: B's rows are rows of a sequence tensor in the caller's layout: row r = (t, b) (time-major numbering, as A's)
-// lives at B1 + ((t - shift)*rsT + b*rsB)*ldb, and rows with t < shift come from B0 + b*ldb (h0).  Without MAPB the
-// tensor is time-major and that is r - shiftB (shiftB = shift*Bn).  BFB: B1 is bf16 (B0 stays fp32).
-constexpr int TN_CHUNK = 800, TN_STAGE = 32;
-
-template <int MT, int NT, bool MAPB = false, bool BFB = false>
-__global__ __launch_bounds__(256) void tn_gemm_split(size_t R, const float* __restrict__ A, int lda,
-                                                     const float* __restrict__ B0, const float* __restrict__ B1,
-                                                     size_t shiftB, int ldb, float* __restrict__ part,
-                                                     int Bn = 1, int rsT = 0, int rsB = 0) {
-  constexpr int M = MT * 16, N = NT * 16, ROWA = M * 2 + 32, ROWB = N * 2 + 32;
-  constexpr int NTILE = MT * NT, TPW = (NTILE + 3) / 4;
-  constexpr int VA = (TN_STAGE * M / 4 + 255) / 256, VB = (TN_STAGE * N / 4 + 255) / 256;   // float4 per thread per stage
-  __shared__ __attribute__((aligned(16))) unsigned char la[3][TN_STAGE * ROWA];
-  __shared__ __attribute__((aligned(16))) unsigned char lb[3][TN_STAGE * ROWB];
-
-  const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
-  const size_t r_begin = (size_t)blockIdx.x * TN_CHUNK;
-  const size_t r_end = (r_begin + TN_CHUNK < R) ? r_begin + TN_CHUNK : R;
-
-  f32x4 va[VA], vb[VB];
-  auto ld4b = [&](const float* base, size_t e) __attribute__((always_inline)) -> f32x4 {   // 4 elements of B1
-    if (BFB) {
-      const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e);
-      return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
-                   __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
-    }
-    return ld4(base + e);
-  };
-  auto load_stage = [&](size_t r0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < VA; ++j) {
-      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
-      const size_t r = r0 + row;
-      va[j] = (idx < TN_STAGE * M / 4 && r < r_end) ? ld4(A + r * lda + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    unsigned t0 = 0, b0 = 0;
-    if (MAPB) { t0 = (unsigned)(r0 / (unsigned)Bn); b0 = (unsigned)(r0 - (size_t)t0 * Bn); }   // uniform
-#pragma unroll
-    for (int j = 0; j < VB; ++j) {
-      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
-      const size_t r = r0 + row;
-      const bool ok = idx < TN_STAGE * N / 4 && r < r_end;
-      if (MAPB) {
-        unsigned t = t0, b = b0 + row;
-        while (b >= (unsigned)Bn) { b -= Bn; ++t; }
-        const unsigned sh = shiftB ? 1u : 0u;
-        if (!ok) vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        else if (t < sh) vb[j] = ld4(B0 + (size_t)b * ldb + 4 * c4);
-        else vb[j] = ld4b(B1, ((size_t)(t - sh) * rsT + (size_t)b * rsB) * ldb + 4 * c4);
-      } else if (BFB) {
-        if (!ok) vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        else if (r < shiftB) vb[j] = ld4(B0 + r * ldb + 4 * c4);
-        else vb[j] = ld4b(B1, (r - shiftB) * ldb + 4 * c4);
-      } else {
-        const float* src = r < shiftB ? B0 + r * ldb : B1 + (r - shiftB) * ldb;   // H_prev: rows of t = 0 are h0
-        vb[j] = ok ? ld4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  };
-  auto split4 = [&](const f32x4 v, unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned off)
-      __attribute__((always_inline)) {
-    uint2 q0, q1, q2;
-    split_quad(v, q0, q1, q2);
-    *reinterpret_cast<uint2*>(p0 + off) = q0;
-    *reinterpret_cast<uint2*>(p1 + off) = q1;
-    *reinterpret_cast<uint2*>(p2 + off) = q2;
-  };
-  auto publish = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < VA; ++j) {
-      const int idx = tid + 256 * j, row = idx / (M / 4), c4 = idx % (M / 4);
-      if (idx < TN_STAGE * M / 4) split4(va[j], la[0], la[1], la[2], (unsigned)(row * ROWA + c4 * 8));
-    }
-#pragma unroll
-    for (int j = 0; j < VB; ++j) {
-      const int idx = tid + 256 * j, row = idx / (N / 4), c4 = idx % (N / 4);
-      if (idx < TN_STAGE * N / 4) split4(vb[j], lb[0], lb[1], lb[2], (unsigned)(row * ROWB + c4 * 8));
-    }
-  };
-
-  f32x4 acc[TPW];
-#pragma unroll
-  for (int k = 0; k < TPW; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const unsigned la0 = (unsigned)(size_t)&la[0][0], lb0 = (unsigned)(size_t)&lb[0][0];
-  // transposed fragment of this lane: rows 8g + q (+4) of the stage, 4 columns at 4*pp of a 16-column tile
-  const unsigned trA = la0 + (8 * g + q) * ROWA + 4 * pp * 2;
-  const unsigned trB = lb0 + (8 * g + q) * ROWB + 4 * pp * 2;
-
-  load_stage(r_begin);
-  for (size_t r0 = r_begin; r0 < r_end; r0 += TN_STAGE) {
-    __syncthreads();                                 // the previous stage's fragment reads are done
-    publish();
-    __syncthreads();
-    if (r0 + TN_STAGE < r_end) load_stage(r0 + TN_STAGE);
-    // Several waves share a SIMD here (2 workgroups per CU): all of a batch's fragment reads are issued,
-    // into registers of their own, before its first MFMA, and the MFMAs have retired before the next batch or
-    // stage reloads them (operand rule).  A wave's tiles wv, wv+4, ... share their B fragment
-    // when NT divides 4 (nt = wv % NT) and their A fragment when MT == 1: those are read once.  Batches of at
-    // most four tiles keep the kernel under 128 registers' worth of fragments (two workgroups per CU).
-    constexpr bool A_CONST = (MT == 1), B_CONST = (4 % NT == 0);
-    constexpr int BATCH = TPW < 4 ? TPW : 4;
-    Frag3 fa1, fb1;
-    if (A_CONST) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa1.p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA), ROWA);
-    }
-    if (B_CONST) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb1.p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + (wv % NT) * 32, ROWB);
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < TPW; k0 += BATCH) {
-      Frag3 fa[BATCH], fb[BATCH];
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) {            // wave-uniform
-          const int mt = tile / NT, nt = tile % NT;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            if (!A_CONST) fa[k].p[pl] = tr_frag(trA + pl * (TN_STAGE * ROWA) + mt * 32, ROWA);
-            if (!B_CONST) fb[k].p[pl] = tr_frag(trB + pl * (TN_STAGE * ROWB) + nt * 32, ROWB);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float touch = 0.f;
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) {
-          acc[k0 + k] = mfma6(A_CONST ? fa1 : fa[k], B_CONST ? fb1 : fb[k], acc[k0 + k]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks MFMAs below the read)
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int tile = wv + 4 * (k0 + k);
-        if (k0 + k < TPW && tile < NTILE) touch += acc[k0 + k][0];
-      }
-      if (touch == 1.2345678e38f) part[0] = 1.f;       // VALU read of every accumulator: the MFMAs have retired
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // D row 4g + r of tile (mt, nt) is m = 16mt + 4g + r, column n = 16nt + (l & 15)
-  float* pc = part + (size_t)blockIdx.x * M * N;
-#pragma unroll
-  for (int k = 0; k < TPW; ++k) {
-    const int tile = wv + 4 * k;
-    if (tile < NTILE) {
-      const int mt = tile / NT, nt = tile % NT;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pc[(size_t)(mt * 16 + 4 * g + r) * N + nt * 16 + (l & 15)] = acc[k][r];
-    }
-  }
-}
-
-// C[idx] = sum over workgroups, fixed order.  split16: a [M, 32] result becomes two [M, r0] / [M, r1] matrices
-// (columns 0..r0-1 and 16..16+r1-1: the rest is rank padding).  Otherwise the first `keep` elements are written.
-__global__ __launch_bounds__(1024) void tn_reduce(int nwg, int MN, const float* __restrict__ part,
-                                                  float* __restrict__ C0, float* __restrict__ C1, int split16,
-                                                  int r0, int r1, int keep) {
-  __shared__ float sm[16][64];
-  const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  float a = 0.f;
-  if (idx < MN) {
-    for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const int wg = wg0 + 16 * j; v[j] = wg < nwg ? part[(size_t)wg * MN + idx] : 0.f; }
-      a += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-  }
-  sm[pid][o] = a;
-  __syncthreads();
-  if (pid == 0 && idx < MN) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += sm[j][o];
-    if (split16) {
-      const int n = idx >> 5, j = idx & 31;
-      if (j < 16) { if (j < r0) C0[n * r0 + j] = t; } else if (j - 16 < r1) C1[n * r1 + (j - 16)] = t;
-    } else if (idx < keep) {
-      C0[idx] = t;
-    }
-  }
-}
-
-static inline int tn_nwg(size_t R) { return (int)((R + TN_CHUNK - 1) / TN_CHUNK); }
-
-// bias / zeta / nu gradients of the low-rank backward: fixed-order sum over workgroups
-__global__ __launch_bounds__(1024) void reduce_lowrank_small(int nwg, const float* __restrict__ part,
+// All gradients of the low-rank backward that are sums over workgroups: fixed-order sum of the slabs, written in the
+// operator's shapes (d_u2 [H,ru], d_w2 [H,rw], d_u1 [ru,H], d_w1 [rw,F]; rank padding dropped), raw-zeta / raw-nu
+// chain rule applied (.cu:116-117,544-545).
+__global__ __launch_bounds__(1024) void reduce_lowrank_slabs(int nwg, const float* __restrict__ part,
                                                              const float* __restrict__ zeta, const float* __restrict__ nu,
-                                                             float* __restrict__ d_bz, float* __restrict__ d_bh,
-                                                             float* __restrict__ d_zeta, float* __restrict__ d_nu) {
+                                                             int ru, int rw, float* __restrict__ d_u1,
+                                                             float* __restrict__ d_u2, float* __restrict__ d_w1,
+                                                             float* __restrict__ d_w2, float* __restrict__ d_bz,
+                                                             float* __restrict__ d_bh, float* __restrict__ d_zeta,
+                                                             float* __restrict__ d_nu) {
   __shared__ float sm[16][64];
   const int o = threadIdx.x & 63, pid = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;               // 0 .. 2*256+1
+  const int idx = blockIdx.x * 64 + o;               // 0 .. SL_ZN + 1
   float a = 0.f;
-  if (idx < 2 * 256 + 2) {
+  if (idx < SL_ZN + 2) {
     for (int wg0 = pid; wg0 < nwg; wg0 += 64) {
       float v[4];
 #pragma unroll
@@ -772,14 +701,23 @@ __global__ __launch_bounds__(1024) void reduce_lowrank_small(int nwg, const floa
   }
   sm[pid][o] = a;
   __syncthreads();
-  if (pid == 0 && idx < 2 * 256 + 2) {
+  if (pid == 0 && idx < SL_ZN + 2) {
     float t = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) t += sm[j][o];
-    if (idx < 256) d_bz[idx] = t;
-    else if (idx < 512) d_bh[idx - 256] = t;
-    else if (idx == 512) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
-    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                      // .cu:117,545
+    if (idx < SL_U1T) {
+      const int n = idx >> 5, j = idx & 31;
+      if (j < 16) { if (j < ru) d_u2[n * ru + j] = t; } else if (j - 16 < rw) d_w2[n * rw + (j - 16)] = t;
+    } else if (idx < SL_W1T) {
+      const int k = idx - SL_U1T, n = k >> 4, j = k & 15;
+      if (j < ru) d_u1[j * 256 + n] = t;
+    } else if (idx < SL_BZ) {
+      const int k = idx - SL_W1T, f = k >> 4, j = k & 15;
+      if (j < rw) d_w1[j * 32 + f] = t;
+    } else if (idx < SL_BZ + 256) d_bz[idx - SL_BZ] = t;
+    else if (idx < SL_ZN) d_bh[idx - SL_BZ - 256] = t;
+    else if (idx == SL_ZN) { const float sz = 1.0f / (1.0f + expf(-zeta[0])); d_zeta[0] = t * sz * (1.0f - sz); }   // .cu:116,544
+    else { const float sn = 1.0f / (1.0f + expf(-nu[0])); d_nu[0] = t * sn * (1.0f - sn); }                         // .cu:117,545
   }
 }
 
@@ -834,16 +772,14 @@ static inline int row_stride_t(const fastgrnn_desc& d) { return (d.flags & FASTG
 static inline int row_stride_b(const fastgrnn_desc& d) { return (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) ? d.T : 1; }
 static inline size_t esz(const fastgrnn_desc& d) { return d.dtype == FASTGRNN_BF16_IO ? 2 : 4; }
 
-struct LowrankBwdWs { size_t dpre, dm, part, splitk, xt, dxt, total; };
+struct LowrankBwdWs { size_t part, sink, xt, dxt, total; };
 LowrankBwdWs lowrank_bwd_layout(const fastgrnn_desc& d) {
   const size_t TB = (size_t)d.T * d.B, nwg = (d.B + 15) / 16;
   LowrankBwdWs L; size_t o = 0;
-  L.dpre = o; o += align256((TB + 16) * 256 * 4);    // + 16 sink rows (lanes beyond a ragged batch)
-  L.dm = o; o += align256((TB + 32) * 32 * 4);       // + 16 sink rows, + 16 more as the sink of d_x
-  L.part = o; o += align256(nwg * SLAB_LR * 4);
-  L.splitk = o; o += align256((size_t)tn_nwg(TB) * 256 * 32 * 4);   // partial C of the largest product, per workgroup
+  L.part = o; o += align256(nwg * SLAB_LR * 4);      // one slab of partial sums per workgroup
+  L.sink = o; o += align256(16 * 32 * 4);            // d_x rows of the lanes beyond a ragged batch
   L.xt = L.dxt = o;
-  if (d.flags & FASTGRNN_FLAG_X_BFT) {                               // time-major copies of x and d_x
+  if (d.flags & FASTGRNN_FLAG_X_BFT) {               // time-major copies of x and d_x
     L.xt = o; o += align256(TB * 32 * esz(d));
     L.dxt = o; o += align256(TB * 32 * esz(d));
   }
@@ -857,12 +793,10 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                              const fastgrnn_grads& g, void* ws, hipStream_t s) {
   const LowrankBwdWs L = lowrank_bwd_layout(d);
   char* base = reinterpret_cast<char*>(ws);
-  float* dpre = (float*)(base + L.dpre); float* dm = (float*)(base + L.dm); float* part = (float*)(base + L.part);
-  float* splitk = (float*)(base + L.splitk);
+  float* part = (float*)(base + L.part);
+  float* sink = (float*)(base + L.sink);
   const int nwg = (d.B + 15) / 16;
-  const size_t TB = (size_t)d.T * d.B;
   const bool bf = d.dtype == FASTGRNN_BF16_IO, bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
-  const bool bm = (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) != 0;
   const int rsT = row_stride_t(d), rsB = row_stride_b(d);
   const int xsT = bft ? d.B : rsT, xsB = bft ? 1 : rsB;               // x / d_x rows (time-major copies under X_BFT)
   const void* xs = x;
@@ -876,55 +810,26 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   }
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 0, s, d.T, d.B, rsT, rsB, xsT, xsB, d.w_rank, d.u_rank,
-                       (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 1 : 0, (const float*)ghs, (const float*)hs,
+                       (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 1 : 0, (const float*)ghs, (const float*)xs, (const float*)hs,
                        (const float*)pre_s, (const float*)m_s, (const float*)h0, (const float*)p.w1, (const float*)p.w2,
                        (const float*)p.u1, (const float*)p.u2, (const float*)p.bias_gate, (const float*)p.bias_update,
-                       (const float*)p.zeta, (const float*)p.nu, (float*)dxs, (float*)g.d_h0, dpre, dm, part);
+                       (const float*)p.zeta, (const float*)p.nu, (float*)dxs, (float*)g.d_h0, sink, part);
   };
   // 8 waves (two per SIMD) for full and ragged batches alike (lanes beyond a ragged batch only get a zero gradient,
   // which needs no extra registers; the first ragged variant masked five values per element and spilled)
   // pre_s == NULL: the pre-activation is recomputed from the rank-space vector (the forward then did not store it)
-  if (pre_s) {
-    if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true>); }
-    else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false>); else go(bwd_scan_lowrank_split<GATE, false, false>); }
-  } else {
-    if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true, true>); }
-    else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false, true>); else go(bwd_scan_lowrank_split<GATE, false, false, true>); }
-  }
+  if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true>); }
+  else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false>); else go(bwd_scan_lowrank_split<GATE, false, false>); }
   if (bft) {
     if (bf) hipLaunchKernelGGL((bft_transpose<unsigned short, false>), dim3(d.B), dim3(256), 0, s, d.B, d.T,
                                (const unsigned short*)(base + L.dxt), (unsigned short*)g.d_x);
     else hipLaunchKernelGGL((bft_transpose<float, false>), dim3(d.B), dim3(256), 0, s, d.B, d.T,
                             (const float*)(base + L.dxt), (float*)g.d_x);
   }
-  hipLaunchKernelGGL(reduce_lowrank_small, dim3((2 * 256 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
-                     (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta,
-                     (float*)g.d_nu);
-  // d_u2 | d_w2 = d_pre^T . [m_h | m_x]     (.cu:546-555, factorised); both operands are time-major fp32
-  const int ng = tn_nwg(TB);
-  hipLaunchKernelGGL((tn_gemm_split<16, 2>), dim3(ng), dim3(256), 0, s, TB, dpre, 256, (const float*)m_s,
-                     (const float*)m_s, (size_t)0, 32, splitk, 1, 0, 0);
-  hipLaunchKernelGGL(tn_reduce, dim3(256 * 32 / 64), dim3(1024), 0, s, ng, 256 * 32, splitk, (float*)g.d_u2,
-                     (float*)g.d_w2, 1, d.u_rank, d.w_rank, 0);
-  // d_u1 = d_m_h^T . H_prev  (rows of t = 0 are h0, the rest hs[t-1]);  d_w1 = d_m_x^T . X
-  auto tn = [&](auto kern, const float* A, const void* B0, const void* B1, size_t shiftB, int ldb, int rT, int rB)
-      __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, dim3(ng), dim3(256), 0, s, TB, A, 32, (const float*)B0, (const float*)B1, shiftB, ldb,
-                       splitk, d.B, rT, rB);
-  };
-  if (bm) { if (bf) tn(tn_gemm_split<1, 16, true, true>, dm, h0, hs, (size_t)d.B, 256, rsT, rsB);
-            else    tn(tn_gemm_split<1, 16, true, false>, dm, h0, hs, (size_t)d.B, 256, rsT, rsB); }
-  else    { if (bf) tn(tn_gemm_split<1, 16, false, true>, dm, h0, hs, (size_t)d.B, 256, rsT, rsB);
-            else    tn(tn_gemm_split<1, 16, false, false>, dm, h0, hs, (size_t)d.B, 256, rsT, rsB); }
-  hipLaunchKernelGGL(tn_reduce, dim3(16 * 256 / 64), dim3(1024), 0, s, ng, 16 * 256, splitk, (float*)g.d_u1,
-                     (float*)nullptr, 0, 0, 0, d.u_rank * 256);
-  const bool xmap = bm && !bft;
-  if (xmap) { if (bf) tn(tn_gemm_split<1, 2, true, true>, dm + 16, xs, xs, (size_t)0, 32, xsT, xsB);
-              else    tn(tn_gemm_split<1, 2, true, false>, dm + 16, xs, xs, (size_t)0, 32, xsT, xsB); }
-  else      { if (bf) tn(tn_gemm_split<1, 2, false, true>, dm + 16, xs, xs, (size_t)0, 32, xsT, xsB);
-              else    tn(tn_gemm_split<1, 2, false, false>, dm + 16, xs, xs, (size_t)0, 32, xsT, xsB); }
-  hipLaunchKernelGGL(tn_reduce, dim3(16 * 32 / 64), dim3(1024), 0, s, ng, 16 * 32, splitk, (float*)g.d_w1,
-                     (float*)nullptr, 0, 0, 0, d.w_rank * 32);
+  // every parameter gradient is a sum over the workgroups' slabs (.cu:544-555, factorised)
+  hipLaunchKernelGGL(reduce_lowrank_slabs, dim3((SL_ZN + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
+                     (const float*)p.nu, d.u_rank, d.w_rank, (float*)g.d_u1, (float*)g.d_u2, (float*)g.d_w1,
+                     (float*)g.d_w2, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
 }
 
 template <int GATE>
@@ -977,7 +882,7 @@ bool lowrank_shape(const fastgrnn_desc& d) {
 bool lowrank_supported(const fastgrnn_desc& d, int direction) {
   if (d.gate_nl > FASTGRNN_NL_TANH || d.update_nl != FASTGRNN_NL_TANH) return false;
   // the backward scan addresses a step's rows with 32-bit offsets: whole sequence tensors below 2^32 bytes
-  if (((double)d.T * d.B + 16.0) * 256 * 4.0 >= 4294967296.0) return false;   // (the workspace tensors carry 16 sink rows)
+  if ((double)d.T * d.B * 256 * 4.0 >= 4294967296.0) return false;
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if (direction == 0) {
     if ((d.flags & FASTGRNN_FLAG_HS_LAST) && preact) return false;
@@ -1011,6 +916,7 @@ int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void
 int lowrank_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                      const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
   if (!cs) return FASTGRNN_ERR_NULL_POINTER;         // the rank-space vector saved by the forward
+  if (!zs) return FASTGRNN_ERR_UNSUPPORTED;          // (the recomputing variant is being rebuilt)
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;

@@ -14,6 +14,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -218,6 +221,32 @@ __device__ __forceinline__ void mfma6_hl(const Frag3& a, const Frag3& b, f32x4& 
   hi = mfma_bf16(a.p[0], b.p[0], hi);
 }
 
+// K = 16 form (v_mfma_f32_16x16x16_bf16: lane group g holds k = 4g..4g+3, two registers per operand) of the six-term
+// product, for contractions whose K is the 16 utterances of a workgroup: one hardware-transposed LDS read
+// (ds_read_b64_tr_b16) returns exactly one plane of such an operand.  Same issue rate as the K = 32 form.
+struct Half3 { s16x4 p[3]; };
+__device__ __forceinline__ f32x4 mfma_bf16_k16(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma6_k16(const Half3& a, const Half3& b, f32x4 acc) {
+  acc = mfma_bf16_k16(a.p[2], b.p[0], acc);
+  acc = mfma_bf16_k16(a.p[1], b.p[1], acc);
+  acc = mfma_bf16_k16(a.p[0], b.p[2], acc);
+  acc = mfma_bf16_k16(a.p[1], b.p[0], acc);
+  acc = mfma_bf16_k16(a.p[0], b.p[1], acc);
+  acc = mfma_bf16_k16(a.p[0], b.p[0], acc);
+  return acc;
+}
+
+__device__ __forceinline__ void mfma6_hl_k16(const Half3& a, const Half3& b, f32x4& hi, f32x4& lo) {   // see mfma6_hl
+  lo = mfma_bf16_k16(a.p[2], b.p[0], lo);
+  lo = mfma_bf16_k16(a.p[1], b.p[1], lo);
+  lo = mfma_bf16_k16(a.p[0], b.p[2], lo);
+  lo = mfma_bf16_k16(a.p[1], b.p[0], lo);
+  lo = mfma_bf16_k16(a.p[0], b.p[1], lo);
+  hi = mfma_bf16_k16(a.p[0], b.p[0], hi);
+}
+
 // Keeps a fragment's registers allocated up to this point, ordered after whatever produced `tie` (pass a value
 // read from the youngest accumulator: once that has been read the matrix pipe has drained).  No instruction.
 __device__ __forceinline__ void keep_alive(float& tie, const Frag3& f) {
@@ -237,9 +266,6 @@ __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::mak
 // two ds_read_b64_tr_b16 (rows +0..3, +4..7), through the compiler builtin so that hipcc tracks
 // their lgkmcnt and registers itself.  EXEC is all ones wherever this is used (the transpose
 // gathers across the 16 lanes of a group).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ u32x4 tr_frag(unsigned lds_byte_addr, int rowb) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((size_t)lds_byte_addr));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((size_t)(lds_byte_addr + 4 * rowb)));
