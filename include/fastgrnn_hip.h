@@ -177,9 +177,10 @@ const char *fastgrnn_hip_status_string(int status);
  *                                 No rank-space vector is saved (c_s is ignored under FASTGRNN_FLAG_SAVE_PREACT).
  * Under FASTGRNN_FLAG_SAVE_PREACT a factorised forward with both ranks in 1..16 also writes, through c_s, the rank-space vector
  * [U1.h_{t-1} | W1.x_t] as a time-major fp32 [T*B, 32] tensor (each half zero-extended to 16 columns) that the
- * backward takes back through c_s.  For these cells z_s may then be NULL in both calls: the forward stores the
- * rank-space vector alone and the backward recomputes the pre-activation from it (0.83 GB less HBM traffic per step
- * at B=4096). */
+ * backward takes back through c_s (with z_s, the pre-activation): its factor gradients are contracted inside the
+ * scan, d_u2|d_w2 against exactly this vector.  (Round 2's option of passing z_s = NULL and having the backward
+ * recompute the pre-activation from c_s is gone: the scan that also contracts the factor gradients has neither the
+ * registers nor the LDS for a second copy of [U2|W2]; z_s = NULL is FASTGRNN_ERR_NULL_POINTER again.) */
 int fastgrnn_hip_kernel_path(const fastgrnn_desc *d, int direction);
 
 /* Workspace sizes in bytes (0 is a valid answer).  Workspace must be 256-B aligned.  The forward answer covers a

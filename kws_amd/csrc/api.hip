@@ -115,10 +115,7 @@ int fastgrnn_hip_backward_unroll(const fastgrnn_desc* d, const fastgrnn_params* 
   const bool preact = (d->flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
   if ((preact || (d->flags & (FASTGRNN_FLAG_BATCH_MAJOR | FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_GRAD_LAST)) || d->dtype == FASTGRNN_BF16_IO) && pick_path(d, 1) != 2)
     return FASTGRNN_ERR_UNSUPPORTED;
-  // (z_s may be NULL under SAVE_PREACT for the register-resident low-rank scans: they recompute the pre-activation
-  // from the rank-space vector in c_s)
-  const bool zs_optional = preact && c_s && pick_path(d, 1) == 2 && lowrank_shape(*d);
-  if (!grad_hs || !x || !hs || (!z_s && !zs_optional) || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
+  if (!grad_hs || !x || !hs || !z_s || (!c_s && !preact) || !h0 || !g) return FASTGRNN_ERR_NULL_POINTER;
   // d_x may be NULL (the input's gradient is not wanted) where it is a GEMM of its own behind the scan
   const bool dx_optional = pick_path(d, 1) == 2 && split_dx_optional(*d);
   if ((!g->d_x && !dx_optional) || !g->d_bias_gate || !g->d_bias_update || !g->d_zeta || !g->d_nu || !g->d_h0)

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     const float* __restrict__ u, const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ d_h0, float* __restrict__ dpre_ws, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[U2L + 2 * PLH2];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[U2L + 3 * PLH2];
   __shared__ __attribute__((aligned(16))) float sinv[16][8];        // 2^-k of slice (utterance, producer wave)
   __shared__ __attribute__((aligned(16))) float sbias[2][H2];
   __shared__ float red[16];
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   const float sz = fsigmoid(zeta[0]), sn = fsigmoid(nu[0]);
   if (PREACT && tid < H2) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
   u32x4* const ulo = reinterpret_cast<u32x4*>(smem); // lo plane of U^T: [(wv*2 + mt)*8 + s][lane]
-  unsigned char* const dpl = smem + U2L;             // [2][PLH2]: hi / lo planes of the scaled d_pre_t, [utterance][unit]
+  unsigned char* const dpl = smem + U2L;             // [3][PLH2]: the three fp16 planes of the scaled d_pre_t, [utterance][unit]
 
   // ---- resident A operands: d_h[k][b] = sum_n U[n][k] d_pre[b][n]; A row i of tile mt is k = 32w + 16mt + i ----
   u32x4 UTh[2][KS2];
@@ -508,12 +508,13 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     if (g == 0) sinv[i][wv] = ldexpf(1.0f, ex - 12);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      uint2 hi, lo;
-      split2h(dpv[mt][0] * dscale, dpv[mt][1] * dscale, hi.x, lo.x);
-      split2h(dpv[mt][2] * dscale, dpv[mt][3] * dscale, hi.y, lo.y);
+      uint2 p0q, p1q, p2q;
+      split3h(dpv[mt][0] * dscale, dpv[mt][1] * dscale, p0q.x, p1q.x, p2q.x);
+      split3h(dpv[mt][2] * dscale, dpv[mt][3] * dscale, p0q.y, p1q.y, p2q.y);
       const unsigned off = (unsigned)(i * ROWH2 + (n0 + 16 * mt) * 2);
-      *reinterpret_cast<uint2*>(dpl + off) = hi;
-      *reinterpret_cast<uint2*>(dpl + PLH2 + off) = lo;
+      *reinterpret_cast<uint2*>(dpl + off) = p0q;
+      *reinterpret_cast<uint2*>(dpl + PLH2 + off) = p1q;
+      *reinterpret_cast<uint2*>(dpl + 2 * PLH2 + off) = p2q;
     }
     SPLIT_STAMP(3)
     lds_barrier();
@@ -528,34 +529,42 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     // fragments of K-step k+1 are requested into the set K-step k-1 used.  Taking one K-step at a time and waiting
     // for its MFMAs before the next request cost 350 cycles per K-step (tools/diag_h256.hip), most of it exposed LDS
     // latency and pipe drain -- and the SIMD's second wave queues behind all of it.
-    struct KOps { Frag2h dB; u32x4 Ul[2]; float inv; };
+    struct KOps { Frag2h dB; u32x4 d2, Ul[2]; float inv; };
     auto req = [&](int k, KOps& o) __attribute__((always_inline)) {
       const unsigned off = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
       o.dB.hi = *reinterpret_cast<const u32x4*>(dpl + off);
       o.dB.lo = *reinterpret_cast<const u32x4*>(dpl + PLH2 + off);
+      o.d2 = *reinterpret_cast<const u32x4*>(dpl + 2 * PLH2 + off);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) o.Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
       o.inv = sinv[i][k] * u_unscale;
     };
+    // Five terms per K-step and row tile (round 3): U^T as two fp16 planes (22 bits: a fixed relative perturbation of
+    // the weights of 2^-23, the size of their own fp32 rounding), d_pre as THREE (exact), the one dropped term
+    // (U^T's low plane against d_pre's third) below 2^-33.  The four small terms go into an accumulator of their own
+    // (inside an MFMA the addends are chopped at the largest one: mfma6_hl).  With three terms -- two
+    // planes of d_pre, lo.lo dropped -- d_zeta / d_nu sat at 4-5.5e-5 of the result at B = 4096 and 4.5e-4 on 8x weights.
     auto issue = [&](int k, const KOps& o, f32x4* pr) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        f32x4 a = mfma_f16(o.Ul[mt], o.dB.hi, z4);                   // small terms first
-        a = mfma_f16(UTh[mt][k], o.dB.lo, a);
-        pr[mt] = mfma_f16(UTh[mt][k], o.dB.hi, a);
+        f32x4 a = mfma_f16(o.Ul[mt], o.dB.lo, z4);                   // smallest first
+        a = mfma_f16(UTh[mt][k], o.d2, a);
+        a = mfma_f16(o.Ul[mt], o.dB.hi, a);
+        pr[2 + mt] = mfma_f16(UTh[mt][k], o.dB.lo, a);
+        pr[mt] = mfma_f16(UTh[mt][k], o.dB.hi, z4);
       }
     };
     auto fold = [&](const KOps& o, const f32x4* pr) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r], o.inv, dh[mt][r]);
+        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r] + pr[2 + mt][r], o.inv, dh[mt][r]);
       // (pinned: without a use here the optimiser sinks the fmas below later requests, and the completion read with
       // them; the operand set stays allocated up to here -- the compiler considers it dead once its MFMAs have ISSUED)
-      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]) : "v"(o.dB.hi), "v"(o.dB.lo), "v"(o.Ul[0]), "v"(o.Ul[1]));
+      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]) : "v"(o.dB.hi), "v"(o.dB.lo), "v"(o.d2), "v"(o.Ul[0]), "v"(o.Ul[1]));
     };
     KOps o0, o1;
-    f32x4 p0[2], p1[2];
+    f32x4 p0[4], p1[4];
     req(0, o0);
     req(1, o1);
     __builtin_amdgcn_sched_barrier(0);

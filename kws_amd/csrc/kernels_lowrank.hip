@@ -110,11 +110,9 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
       if (AUX == 1) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) { st4(zs + o + 4 * mt, gt.z[mt]); st4(cs + o + 4 * mt, gt.c[mt]); }
-      } else if (AUX == 2 || AUX == 3) {             // (3: the rank-space vector alone -- the backward recomputes the
-        if (AUX == 2) {                              //  pre-activation from it, bwd_scan_lowrank_split<.., RECOMP>)
+      } else if (AUX == 2) {
 #pragma unroll
-          for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);    // gt.z carries the pre-activation
-        }
+        for (int mt = 0; mt < NT; ++mt) st4(zs + o + 4 * mt, gt.z[mt]);      // gt.z carries the pre-activation
         // [m_h | m_x] of the step: cs is [T,B,32] in this mode; every wave holds the same sum, wave w
         // stores lane groups g == w (8 floats each)
         if (g == wv) {
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_scan_lowrank_split(
         mhi += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][8 * g + 4]);
       }
     }
-    if (AUX == 2 || AUX == 3) { gout.mlo = mlo; gout.mhi = mhi; }     // stored with the step's other outputs
+    if (AUX == 2) { gout.mlo = mlo; gout.mhi = mhi; }                 // stored with the step's other outputs
     const Frag3 mB = split3(mlo, mhi);
     // ---- B: pre-activation tiles, epilogue of tile k under the MFMAs of tile k+1 -----------------
     f32x4 acc[NT];
@@ -265,18 +263,17 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   // 8 waves (two per SIMD), 32 units each (two 16-row tiles, one K-step over the own units): see fwd_scan_lowrank_split
   constexpr int H = 256, F = 32, NW = 8, UPW = H / NW, NT = UPW / 16, UPL = UPW / 4, MROW = 36;
   constexpr int IMG_PLANE = 1024;                    // one plane of an image: 16 utterances x 64 bytes
-  // rank-space partials of the eight waves and their sum: two barriers per step (every thread adds ONE value's eight
-  // partials, as in the forward; a wave that read all eight partials itself held 64 registers of them at once,
-  // which this kernel does not have), so neither buffer needs a second copy
-  __shared__ __attribute__((aligned(16))) float mp[NW][16][MROW];
-  __shared__ __attribute__((aligned(16))) float msum[16][MROW];
+  // rank-space partials of the eight waves, by step parity (ONE barrier per step: a wave may write the next step's
+  // partial while another still sums this step's)
+  __shared__ __attribute__((aligned(16))) float mp[2][NW][16][MROW];
   __shared__ __attribute__((aligned(16))) float sbias[2][H];
   __shared__ float red[2 * NW];
   __shared__ __attribute__((aligned(16))) unsigned char wimg[NW][3 * IMG_PLANE];   // wave-private: d_pre_t, h_{t-1}, d_m_t
-  __shared__ __attribute__((aligned(16))) unsigned char simg[2][3 * IMG_PLANE];    // shared: m_t [b][32 j], x_t [b][32 f]
+  __shared__ __attribute__((aligned(16))) unsigned char simg[2][2][3 * IMG_PLANE]; // shared, by step parity: m_t [b][32 j], x_t [b][32 f]
   // The factor fragments are PARKED in LDS in fragment order and read back each step for the phase that uses them
-  // ([U2|W2]^T in front of the first barrier, U1^T and W1^T behind the second): registers are what this kernel is
-  // short of (28 accumulators + a step of operands in flight), LDS bandwidth is not.
+  // ([U2|W2]^T in front of the barrier, U1^T and W1^T behind it): registers are what this kernel is short of (28
+  // accumulators + a step of operands in flight + the operands of the products that trail into the next step), LDS
+  // bandwidth is not.
   __shared__ __attribute__((aligned(16))) u32x4 uw2tl[NW][2][3][64];
   __shared__ __attribute__((aligned(16))) uint2 u1tl[NW][NT][3][64];
   __shared__ __attribute__((aligned(16))) uint2 w1tl[2][3][64];
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   const float sn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fsigmoid(nu[0]))));
   if (tid < H) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
 
-  // ---- A operands, parked ---------------------------------------------------------------------
+  // ---- A operands ---------------------------------------------------------------------------
   // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units (K = 32): tile 0 rows = U2 columns, tile 1 = W2 columns
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
@@ -371,7 +368,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   const unsigned wr_off = (unsigned)(i * 64 + g * 16);
   const unsigned tr_lane = (unsigned)((4 * g + (i >> 2)) * 64 + (i & 3) * 8);
   const unsigned tr_off = (unsigned)(size_t)my_img + tr_lane;
-  const unsigned trs_off = (unsigned)(size_t)&simg[0][0] + tr_lane;
+  const unsigned trs_off = (unsigned)(size_t)&simg[0][0][0] + tr_lane;
   auto img_fence = []() __attribute__((always_inline)) { asm volatile("" ::: "memory"); };   // (compiler ordering only)
   auto put_img = [&](const Frag3& f) __attribute__((always_inline)) {
     img_fence();
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   // Shared images: thread (su, sc) = (tid >> 5, tid & 31) owns value sc of utterance su of m_t and of x_t
   const int su = tid >> 5, sc = tid & 31;
   const int sb = blockIdx.x * 16 + su, sbc = (!RAGGED || sb < B) ? sb : B - 1;
-  unsigned char* const my_s = &simg[0][0] + su * 64 + sc * 2;
+  unsigned char* const my_s = &simg[0][0][0] + su * 64 + sc * 2;
   auto fresh_lane = [&]() __attribute__((always_inline)) { unsigned v = (unsigned)l; asm volatile("" : "+v"(v)); return v; };
 
   // grad_hs, pre-activation, h_prev of the lane's 8 units; one value of the step's rank-space vector and frame
@@ -421,18 +418,23 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     }
     return bld4(r, voff, soff);
   };
-  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
+  // The refill of the operand set is issued in three parts, each right behind the last use of what it overwrites
+  // (requests spread over the step queue less in the CU's one address unit than a burst of all eight waves' requests)
+  auto load_ew_ga = [&](int t, EwOps& e, int mt) __attribute__((always_inline)) {    // grad_hs, pre-activation of row tile mt
     // wave-uniform offsets of step t's rows (scalar registers)
     const unsigned step = (unsigned)t * (unsigned)rsT * H;                   // elements
-    const unsigned gstep = glast ? 0u : step, hstep = step - (unsigned)rsT * H;
+    const unsigned gstep = glast ? 0u : step;
     const bool gzero = (RAGGED && !valid) || (glast && t != Tn - 1);
+    // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero, so gg,
+    // d_pre and every sum or product they enter stay exactly zero for them; see bwd_scan_split_w8)
+    const f32x4 gv = bld4s(r_g, lane_g * ESZ, (gstep + 4 * mt) * ESZ);
+    e.g[mt] = gzero ? f32x4{0.f, 0.f, 0.f, 0.f} : gv;
+    e.a0[mt] = bld4(r_pre, lane_h * 4u, (step + 4 * mt) * 4u);
+  };
+  auto load_ew_h = [&](int t, EwOps& e) __attribute__((always_inline)) {     // h_prev
+    const unsigned hstep = (unsigned)t * (unsigned)rsT * H - (unsigned)rsT * H;
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-      // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero, so gg,
-      // d_pre and every sum or product they enter stay exactly zero for them; see bwd_scan_split_w8)
-      const f32x4 gv = bld4s(r_g, lane_g * ESZ, (gstep + 4 * mt) * ESZ);
-      e.g[mt] = gzero ? f32x4{0.f, 0.f, 0.f, 0.f} : gv;
-      e.a0[mt] = bld4(r_pre, lane_h * 4u, (step + 4 * mt) * 4u);
       // h_prev of step 0 is h0 (.cu:478-481).  fp32: one load whose descriptor and offsets are selected in scalar
       // registers (no branch); bf16 sequences: h0 is fp32, a different load
       if (BF) {
@@ -442,27 +444,65 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
         e.h[mt] = bld4(t == 0 ? r_h0 : r_hs, (t == 0 ? lane_0 : lane_h) * 4u, (t == 0 ? 4u * mt : hstep + 4 * mt) * 4u);
       }
     }
+  };
+  auto load_ew_mx = [&](int t, EwOps& e) __attribute__((always_inline)) {    // one value of m_t and of x_t
     e.m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_m, (int)lane_m1, (int)((unsigned)t * (unsigned)B * 128u), 0));
     const unsigned xstep = (unsigned)t * (unsigned)xsT * F * ESZ;
     if (BF) e.x1 = bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r_x, (int)lane_x1, (int)xstep, 0));
     else e.x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, (int)lane_x1, (int)xstep, 0));
   };
+  auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) { load_ew_ga(t, e, 0); load_ew_ga(t, e, 1); load_ew_h(t, e); load_ew_mx(t, e); };
 
-  // transposed operands of the step's d_u1^T / d_w1^T products.  They are loop-carried on purpose: those products are
-  // the step's youngest MFMAs and nothing of the recurrence depends on them, so their completion read sits BEHIND the
-  // next step's element-wise work, and until then these registers stay allocated (operand rule)
-  Half3 Ahp[NT], Bdm, Ax, Bdmx;
+  // Transposed operands of the step's factor-gradient products.  They are loop-carried on purpose: those products
+  // trail behind the recurrence's (nothing of it depends on them) and run in the matrix pipe UNDER the next step's
+  // element-wise work; their completion read sits behind that work, and until then these registers stay allocated
+  // (operand rule)
+  Half3 Adp[NT], Bm[2], Ahp[NT], Bdm, Ax, Bdmx;
   {
     const s16x4 z4 = s16x4{0, 0, 0, 0};
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) { Ahp[0].p[pl] = z4; Ahp[1].p[pl] = z4; Bdm.p[pl] = z4; Ax.p[pl] = z4; Bdmx.p[pl] = z4; }
+    for (int pl = 0; pl < 3; ++pl) {
+      Adp[0].p[pl] = z4; Adp[1].p[pl] = z4; Bm[0].p[pl] = z4; Bm[1].p[pl] = z4;
+      Ahp[0].p[pl] = z4; Ahp[1].p[pl] = z4; Bdm.p[pl] = z4; Ax.p[pl] = z4; Bdmx.p[pl] = z4;
+    }
   }
+  auto trailing_done = [&]() __attribute__((always_inline)) {
+    // read of the youngest factor-gradient accumulator = every MFMA issued so far has retired (they retire in order)
+    float tie = accU1[NT - 1][0];
+    asm volatile("" : "+v"(tie)
+                 : "v"(Adp[0].p[0]), "v"(Adp[0].p[1]), "v"(Adp[0].p[2]), "v"(Adp[1].p[0]), "v"(Adp[1].p[1]), "v"(Adp[1].p[2]),
+                   "v"(Bm[0].p[0]), "v"(Bm[0].p[1]), "v"(Bm[0].p[2]), "v"(Bm[1].p[0]), "v"(Bm[1].p[1]), "v"(Bm[1].p[2]),
+                   "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
+                   "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
+                   "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
+    if (tie == 1.2345678e38f) red[0] = 1.f;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The factor-gradient products of a step (.cu:546-555): d_u2 | d_w2 += d_pre^T . [m_h | m_x], d_w1^T += x^T . d_m_x,
+  // d_u1^T += h_prev^T . d_m_h -- the last in EVERY wave, so that one read of accU1 (trailing_done) proves that all of
+  // them have retired.  Every wave issues the d_w1 product (its operands stay zero outside waves 2 and 3): no branch
+  // inside the block these MFMAs share with the element-wise work.
+  auto trailing_products_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) accUW[a][c] = mfma6_k16(Adp[a], Bm[c], accUW[a][c]);
+  };
+  auto trailing_products_b = [&]() __attribute__((always_inline)) {
+    accW1 = mfma6_k16(Ax, Bdmx, accW1);
+#pragma unroll
+    for (int a = 0; a < NT; ++a) accU1[a] = mfma6_k16(Ahp[a], Bdm, accU1[a]);
+  };
+  constexpr int N_TRAILING_A = NT * 2 * 6, N_TRAILING_B = (1 + NT) * 6;
   auto step = [&](int t, EwOps& e) __attribute__((always_inline)) {
+    const int cur = t & 1;
+    // ---- the PREVIOUS step's factor-gradient products are issued one by one BETWEEN the instructions of EW(t): two waves
+    //      of a SIMD in the same phase do not overlap each other's matrix and vector work (a wave waits at the issue of
+    //      an MFMA while the pipe is busy), the instruction stream of ONE wave does, for half of each MFMA's cycles
     // ---- EW(t): .cu:107-117 ------------------------------------------------------------------
     f32x4 dpv[NT];
     float sz8 = 0.f, sn8 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
+    auto ew_tile = [&](int mt) __attribute__((always_inline)) {
       const f32x4 bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 4 * mt]);
       const f32x4 bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 4 * mt]);
 #pragma unroll
@@ -478,43 +518,50 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
         dpv[mt][r] = dzp + dcp;                                                   // .cu:113
         dh[mt][r] = zg;
       }
-    }
+    };
+    trailing_products_a(); trailing_products_b();
+    ew_tile(0); ew_tile(1);
     kahan_add(pz, pz_c, sz8); kahan_add(pn, pn_c, sn8);
-    {
-      // completion read of the PREVIOUS step's youngest products (see Ahp): from here on their operand registers are free
-      float tie = accU1[NT - 1][0];
-      asm volatile("" : "+v"(tie)
-                   : "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
-                     "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
-                     "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
-      if (tie == 1.2345678e38f) red[0] = 1.f;
-      __builtin_amdgcn_sched_barrier(0);
+    // (the element-wise results are pinned HERE, in front of the scheduling directives: arithmetic is not ordered
+    // against them otherwise and would be emitted behind the block's closing barrier)
+    asm volatile("" : "+v"(dpv[0]), "+v"(dpv[1]), "+v"(dh[0]), "+v"(dh[1]), "+v"(sbz[0]), "+v"(sbz[1]), "+v"(sbh[0]),
+                 "+v"(sbh[1]), "+v"(pz), "+v"(pn), "+v"(pz_c), "+v"(pn_c));
+#pragma unroll
+    for (int k = 0; k < N_TRAILING_A + N_TRAILING_B; ++k) {   // one MFMA, three vector instructions (the transcendentals go where they fit), ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    trailing_done();                                 // ... all retired: their operand registers are free from here
     SPLIT_STAMP(0)
     // ---- planes of d_pre_t (B operand of the rank-space partial as they are; transposed, the A operand of the
     //      d_u2|d_w2 products) and of h_{t-1} through the private image; one value each of m_t and x_t into the shared ones
+    if (t > 0) { load_ew_ga(t - 1, e, 0); load_ew_ga(t - 1, e, 1); }   // (EW(t) has consumed them; the previous step's MFMAs have retired)
+    __builtin_amdgcn_sched_barrier(0);
     const Frag3 dfr = split3(dpv[0], dpv[1]);
-    Half3 Adp[NT];
     put_img(dfr);
     tr_half(0, Adp[0]); tr_half(1, Adp[1]);
-    put_img(split3(e.h[0], e.h[1]));                 // (stays in the image until the products behind the barriers want it)
+    put_img(split3(e.h[0], e.h[1]));                 // (stays in the image until the products behind the barrier want it)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t > 0) load_ew_h(t - 1, e);
+    __builtin_amdgcn_sched_barrier(0);
     {
+      unsigned char* const so = my_s + cur * (6 * IMG_PLANE);
       unsigned short s0, s1, s2;
       split_one(e.m1, s0, s1, s2);
-      *reinterpret_cast<unsigned short*>(my_s) = s0;
-      *reinterpret_cast<unsigned short*>(my_s + IMG_PLANE) = s1;
-      *reinterpret_cast<unsigned short*>(my_s + 2 * IMG_PLANE) = s2;
+      *reinterpret_cast<unsigned short*>(so) = s0;
+      *reinterpret_cast<unsigned short*>(so + IMG_PLANE) = s1;
+      *reinterpret_cast<unsigned short*>(so + 2 * IMG_PLANE) = s2;
       split_one(e.x1, s0, s1, s2);
-      *reinterpret_cast<unsigned short*>(my_s + 3 * IMG_PLANE) = s0;
-      *reinterpret_cast<unsigned short*>(my_s + 4 * IMG_PLANE) = s1;
-      *reinterpret_cast<unsigned short*>(my_s + 5 * IMG_PLANE) = s2;
+      *reinterpret_cast<unsigned short*>(so + 3 * IMG_PLANE) = s0;
+      *reinterpret_cast<unsigned short*>(so + 4 * IMG_PLANE) = s1;
+      *reinterpret_cast<unsigned short*>(so + 5 * IMG_PLANE) = s2;
     }
     Frag3 UW2Tf[2];
     load_uw2t(UW2Tf);
-    // EW(t) has consumed the operand set (and the previous step's MFMAs have retired): refill it for t-1
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
-    if (t > 0) load_ew(t - 1, e);
+    if (t > 0) load_ew_mx(t - 1, e);
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(2)
     // ---- rank-space partial over own units: B operand = this lane's fragment of d_pre ----
@@ -524,46 +571,36 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     mfma6_hl(UW2Tf[0], dfr, mh, mhl);
     mfma6_hl(UW2Tf[1], dfr, mx, mxl);
     __builtin_amdgcn_sched_barrier(0);
-    *reinterpret_cast<f32x4*>(&mp[wv][i][4 * g]) = mh + mhl;
-    *reinterpret_cast<f32x4*>(&mp[wv][i][16 + 4 * g]) = mx + mxl;
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][4 * g]) = mh + mhl;
+    *reinterpret_cast<f32x4*>(&mp[cur][wv][i][16 + 4 * g]) = mx + mxl;
     SPLIT_STAMP(3)
     lds_barrier();
-    {
-      // 512 threads = 16 utterances x 32 values: each adds one value's eight partials, in wave order
-      const int u = tid & 15, j = tid >> 4;
-      float sj = 0.f;
-#pragma unroll
-      for (int w2i = 0; w2i < NW; ++w2i) sj += mp[w2i][u][j];
-      msum[u][j] = sj;
-    }
-    // d_u2 | d_w2 += d_pre_t^T . [m_h | m_x]_t  (.cu:546-555): between the barriers, where a wave otherwise waits
-    Half3 Bm[2];
-    {
-      tr_half_at(trs_off, Bm[0]); tr_half_at(trs_off + 32, Bm[1]);
-      if (xwave) tr_half_at(trs_off + 3 * IMG_PLANE + (wv & 1) * 32, Ax);   // (x_t's image is rewritten behind the next barrier)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) accUW[a][c] = mfma6_k16(Adp[a], Bm[c], accUW[a][c]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    lds_barrier();
     SPLIT_STAMP(4)
-    // ---- [d_m_h | d_m_x]_t of utterance i: rank rows 4g..4g+3 of either half ------------------------------
-    const f32x4 dmh = *reinterpret_cast<const f32x4*>(&msum[i][4 * g]);
-    const f32x4 dmx = *reinterpret_cast<const f32x4*>(&msum[i][16 + 4 * g]);
-    uint2 h0q, h1q, h2q, x0q, x1q, x2q;
-    split_quad(dmh, h0q, h1q, h2q);
-    split_quad(dmx, x0q, x1q, x2q);
+    // ---- behind the barrier: operands of everything that follows, then [d_m_h | d_m_x]_t of utterance i (rank rows
+    //      4g..4g+3 of either half) as the sum of the eight partials, in wave order
+    const unsigned trs_cur = trs_off + cur * (6 * IMG_PLANE);
+    tr_half_at(trs_cur, Bm[0]); tr_half_at(trs_cur + 32, Bm[1]);
+    if (xwave) tr_half_at(trs_cur + 3 * IMG_PLANE + (wv & 1) * 32, Ax);
+    Half3 U1Tf[NT], W1Tf;
+    load_u1t(U1Tf);
+    if (wv < 2) load_w1t(W1Tf);
+    f32x4 dmh = f32x4{0.f, 0.f, 0.f, 0.f}, dmx = dmh;
+#pragma unroll
+    for (int w2i = 0; w2i < NW; ++w2i) dmh += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][4 * g]);
+    if (wv < 4) {                                    // (wave-uniform) d_x in waves 0, 1; d_w1 in waves 2, 3
+#pragma unroll
+      for (int w2i = 0; w2i < NW; ++w2i) dmx += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][16 + 4 * g]);
+    }
     Half3 mBh, mBx;
-    mBh.p[0] = __builtin_bit_cast(s16x4, h0q); mBh.p[1] = __builtin_bit_cast(s16x4, h1q); mBh.p[2] = __builtin_bit_cast(s16x4, h2q);
-    mBx.p[0] = __builtin_bit_cast(s16x4, x0q); mBx.p[1] = __builtin_bit_cast(s16x4, x1q); mBx.p[2] = __builtin_bit_cast(s16x4, x2q);
+    {
+      uint2 q0, q1, q2;
+      split_quad(dmh, q0, q1, q2);
+      mBh.p[0] = __builtin_bit_cast(s16x4, q0); mBh.p[1] = __builtin_bit_cast(s16x4, q1); mBh.p[2] = __builtin_bit_cast(s16x4, q2);
+      split_quad(dmx, q0, q1, q2);
+      mBx.p[0] = __builtin_bit_cast(s16x4, q0); mBx.p[1] = __builtin_bit_cast(s16x4, q1); mBx.p[2] = __builtin_bit_cast(s16x4, q2);
+    }
     // ---- d_old_h for the own units (C-in = z*g) and d_x ---------------------------------------------
     {
-      Half3 U1Tf[NT], W1Tf;
-      load_u1t(U1Tf);
-      if (wv < 2) load_w1t(W1Tf);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 dlo[NT];
 #pragma unroll
@@ -580,34 +617,25 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt) dh[mt] += dlo[mt];
-      // (this sum read the youngest of the products above: their operand registers are free for the reads below --
-      // and so are, only now, those of the d_u2|d_w2 products issued between the barriers, which nothing else has
-      // waited for: kept allocated up to here)
-      asm volatile("" : "+v"(dh[0]), "+v"(dh[1])
-                   : "v"(Adp[0].p[0]), "v"(Adp[0].p[1]), "v"(Adp[0].p[2]), "v"(Adp[1].p[0]), "v"(Adp[1].p[1]), "v"(Adp[1].p[2]),
-                     "v"(Bm[0].p[0]), "v"(Bm[0].p[1]), "v"(Bm[0].p[2]), "v"(Bm[1].p[0]), "v"(Bm[1].p[1]), "v"(Bm[1].p[2]));
+      // (this sum read the youngest of the products above: their operand registers are free for the reads below)
+      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]));
       __builtin_amdgcn_sched_barrier(0);
     }
     SPLIT_STAMP(5)
-    // ---- h_{t-1} comes back out of the private image, transposed; then the planes of [d_m_h | d_m_x]_t go through it:
-    //      the B operand of d_u1^T (columns 0..15) and d_w1^T (16..31)
+    // ---- operands of the step's factor-gradient products (issued inside the next step's element-wise work):
+    // h_{t-1} comes back out of the private image, transposed; then the planes of [d_m_h | d_m_x]_t go through it:
+    // the B operand of d_u1^T (columns 0..15) and, in waves 2 and 3, of d_w1^T (16..31)
     tr_half(0, Ahp[0]); tr_half(1, Ahp[1]);          // (in front of the image's next use: LDS runs a wave's instructions in order)
     img_fence();
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + g * 8) = mBh.p[pl];
-      *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + 32 + g * 8) = mBx.p[pl];
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + g * 8) = mBh.p[pl];
+    if (xwave) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<s16x4*>(my_img + pl * IMG_PLANE + i * 64 + 32 + g * 8) = mBx.p[pl];
     }
     img_fence();
     tr_half(0, Bdm);
     if (xwave) tr_half(1, Bdmx);
-    __builtin_amdgcn_sched_barrier(0);
-    // d_w1^T += x_t^T . d_m_x,t (waves 2, 3), then d_u1^T += h_{t-1}^T . d_m_h,t -- the step's youngest products in
-    // EVERY wave: one read of accU1 proves the whole step has retired
-    if (xwave) accW1 = mfma6_k16(Ax, Bdmx, accW1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int a = 0; a < NT; ++a) accU1[a] = mfma6_k16(Ahp[a], Bdm, accU1[a]);
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(6)
   };
@@ -616,19 +644,12 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   __syncthreads();                                   // sbias, parked fragments
   load_ew(Tn - 1, ea);
   for (int t = Tn - 1; t >= 0; --t) step(t, ea);
+  trailing_products_a(); trailing_products_b();      // step 0's
+  __builtin_amdgcn_sched_barrier(0);
 #ifdef FASTGRNN_DIAG_STAMPS
   if (blockIdx.x == 7 && (tid & 63) == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
 #endif
-  {
-    // the last step's MFMAs have retired before anything below may reuse their operand registers
-    float tie = accU1[NT - 1][0];
-    asm volatile("" : "+v"(tie)
-                 : "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
-                   "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
-                   "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
-    if (tie == 1.2345678e38f) red[0] = 1.f;
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  trailing_done();                                   // the last step's MFMAs have retired before anything below reuses their operand registers
   // ---- flush ---------------------------------------------------------------------------------
   // (lane geometry recomputed from the lane id: nothing of it has to stay in a register across the scan)
   const unsigned lf = fresh_lane();
@@ -817,7 +838,6 @@ void launch_bwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
   };
   // 8 waves (two per SIMD) for full and ragged batches alike (lanes beyond a ragged batch only get a zero gradient,
   // which needs no extra registers; the first ragged variant masked five values per element and spilled)
-  // pre_s == NULL: the pre-activation is recomputed from the rank-space vector (the forward then did not store it)
   if (bf) { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, true>); else go(bwd_scan_lowrank_split<GATE, false, true>); }
   else    { if (d.B % 16) go(bwd_scan_lowrank_split<GATE, true, false>); else go(bwd_scan_lowrank_split<GATE, false, false>); }
   if (bft) {
@@ -851,17 +871,14 @@ void launch_fwd_lowrank_gate(const fastgrnn_desc& d, const fastgrnn_params& p, c
                        (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta, (const float*)p.nu,
                        (float*)hs, (float*)zs, (float*)cs);
   };
-  // SAVE_PREACT with z_s == NULL: only the rank-space vector is saved (the backward recomputes the pre-activation)
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  const int aux = zs == nullptr ? ((preact && cs) ? 3 : 0) : (preact ? 2 : 1);
+  const int aux = zs == nullptr ? 0 : (preact ? 2 : 1);
   auto pick = [&](auto bf_tag) __attribute__((always_inline)) {
     constexpr bool BFv = decltype(bf_tag)::value;
     if (d.flags & FASTGRNN_FLAG_HS_LAST) {           // inference: aux == 0 (lowrank_forward)
       if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, BFv, true>); else go(fwd_scan_lowrank_split<GATE, 0, false, BFv, true>);
     } else if (aux == 2) {
       if (ragged) go(fwd_scan_lowrank_split<GATE, 2, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 2, false, BFv>);
-    } else if (aux == 3) {
-      if (ragged) go(fwd_scan_lowrank_split<GATE, 3, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 3, false, BFv>);
     } else if (aux == 0) {
       if (ragged) go(fwd_scan_lowrank_split<GATE, 0, true, BFv>); else go(fwd_scan_lowrank_split<GATE, 0, false, BFv>);
     } else if constexpr (!BFv) {                     // the reference's (z_s, h_prime_s) outputs: fp32 sequences
@@ -901,7 +918,7 @@ size_t lowrank_backward_ws(const fastgrnn_desc& d) { return lowrank_bwd_layout(d
 int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,
                     void* cs, void* ws, hipStream_t s) {
   const bool preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
-  if (preact && !cs) return FASTGRNN_ERR_NULL_POINTER;   // (z_s may be NULL: the rank-space vector alone is saved)
+  if (preact && (!cs || !zs) && !(d.flags & FASTGRNN_FLAG_HS_LAST)) return FASTGRNN_ERR_NULL_POINTER;   // pre-activation and rank-space vector
   if ((d.flags & FASTGRNN_FLAG_HS_LAST) && (zs || (preact && cs))) return FASTGRNN_ERR_UNSUPPORTED;
   if (d.dtype == FASTGRNN_BF16_IO && zs && !preact) return FASTGRNN_ERR_UNSUPPORTED;
   if ((d.flags & FASTGRNN_FLAG_X_BFT) && !ws) return FASTGRNN_ERR_WORKSPACE;
@@ -915,8 +932,7 @@ int lowrank_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void
 
 int lowrank_backward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* ghs, const void* x, const void* hs,
                      const void* zs, const void* cs, const void* h0, const fastgrnn_grads& g, void* ws, hipStream_t s) {
-  if (!cs) return FASTGRNN_ERR_NULL_POINTER;         // the rank-space vector saved by the forward
-  if (!zs) return FASTGRNN_ERR_UNSUPPORTED;          // (the recomputing variant is being rebuilt)
+  if (!cs || !zs) return FASTGRNN_ERR_NULL_POINTER;  // the rank-space vector and the pre-activation saved by the forward
   switch (d.gate_nl) {
     case FASTGRNN_NL_SIGMOID: launch_bwd_lowrank_gate<FASTGRNN_NL_SIGMOID>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;
     case FASTGRNN_NL_RELU: launch_bwd_lowrank_gate<FASTGRNN_NL_RELU>(d, p, ghs, x, hs, zs, cs, h0, g, ws, s); break;

@@ -172,6 +172,16 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned
   hi = __builtin_bit_cast(unsigned, f16x2{ha, hb});
   lo = __builtin_bit_cast(unsigned, f16x2{la, lb});
 }
+// three fp16 planes: exact for a value scaled into fp16's normal range (11 + 11 + 11 bits cover fp32's 24)
+__device__ __forceinline__ void split3h(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  const float ra = a - (float)ha, rb = b - (float)hb;
+  const _Float16 la = (_Float16)ra, lb = (_Float16)rb;
+  const _Float16 ma = (_Float16)(ra - (float)la), mb = (_Float16)(rb - (float)lb);
+  p0 = __builtin_bit_cast(unsigned, f16x2{ha, hb});
+  p1 = __builtin_bit_cast(unsigned, f16x2{la, lb});
+  p2 = __builtin_bit_cast(unsigned, f16x2{ma, mb});
+}
 __device__ __forceinline__ Frag2h split2h8(const f32x4 lo4, const f32x4 hi4) {
   unsigned h[4], l[4];
   split2h(lo4[0], lo4[1], h[0], l[0]); split2h(lo4[2], lo4[3], h[1], l[1]);

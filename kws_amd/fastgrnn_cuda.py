@@ -195,7 +195,7 @@ def kernel_path(T, B, F, H, w_rank=0, u_rank=0, gate_nl=0, update_nl=2, dtype=to
 
 
 def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1, w2, u1, u2,
-                  unrolled, update_nl, want_gates, flags, keep_preact=True):
+                  unrolled, update_nl, want_gates, flags):
     lib = _lib.load()
     _check_input(input, "input")
     _check_input(bias_gate, "bias_gate"); _check_input(bias_update, "bias_update")
@@ -242,8 +242,6 @@ def _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, h0, gate_nl, w1
             # factorised operands: the forward also saves the rank-space vector [U1.h | W1.x] per step, always
             # time-major and zero-extended to 16 + 16 columns (an opaque tensor for the backward)
             cs = torch.empty((T * B, 32), dtype=pdt, device=dev)
-            if not keep_preact and plan[1] == 2:
-                zs = None            # ... and that vector is all the backward needs: it recomputes the pre-activation
         # (dense H=128 layers with a wide input keep the frame product in the workspace only when no auxiliary
         # output is requested: include/fastgrnn_hip.h, forward workspace)
         wide = desc.H == 128 and desc.F > 32 and not desc.w_rank and not desc.u_rank
@@ -266,7 +264,6 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
                    unrolled, update_nl, flags, bias_gate=None, bias_update=None, need_dx=True):
     lib = _lib.load()
     preact = bool(flags & _lib.FLAG_SAVE_PREACT)
-    no_pre = False
     if preact:
         if bias_gate is None or bias_update is None:
             raise RuntimeError("FLAG_SAVE_PREACT backward needs bias_gate and bias_update")
@@ -274,12 +271,9 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         # run on the dense kernels and save the pre-activation alone)
         rank_space = h_prime if (_present(w1) and _present(u1) and w1.shape[0] <= 16 and u1.shape[0] <= 16
                                  and tuple(w1.shape[1:]) == (32,) and u1.shape[1] == 256) else None
-        no_pre = rank_space is not None and z.numel() == 0     # the forward saved the rank-space vector alone
-        if no_pre:
-            z = torch.empty(tuple(hs_or_old_h.shape), dtype=_param_dtype(input.dtype), device="meta")   # shape checks only
         if rank_space is not None:
             _check_input(rank_space, "rank_space")
-            _expect(rank_space, (z.numel() // z.shape[-1], 32), "rank_space")
+            _expect(rank_space, (hs_or_old_h.numel() // hs_or_old_h.shape[-1], 32), "rank_space")
         h_prime = z              # keeps the shape checks below uniform
     for t, n in ((grad_h, "grad_h"), (input, "input"), (hs_or_old_h, "hidden_states" if unrolled else "old_h"),
                  (z, "z"), (h_prime, "h_prime"), (h0, "initial_h")):
@@ -349,7 +343,7 @@ def _backward_impl(grad_h, input, hs_or_old_h, zeta, nu, w, u, z, h_prime, h0, w
         with _Timed("backward", dev):
             if unrolled:
                 st = lib.fastgrnn_hip_backward_unroll(C.byref(desc), C.byref(params), _ptr(grad_h), _ptr(input),
-                                                      _ptr(hs_or_old_h), C.c_void_p(None) if no_pre else _ptr(z),
+                                                      _ptr(hs_or_old_h), _ptr(z),
                                                       _ptr(rank_space if preact else h_prime),
                                                       _ptr(h0), C.byref(grads), wsp, nbytes, _stream(dev))
             else:
@@ -378,12 +372,12 @@ def backward(grad_h, input, old_h, zeta, nu, w, u, z, h_prime, w1, w2, u1, u2, z
 
 
 def forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_non_linearity,
-                   w1, w2, u1, u2, *, update_non_linearity=2, want_gates=True, flags=0, keep_preact=True):
+                   w1, w2, u1, u2, *, update_non_linearity=2, want_gates=True, flags=0):
     """fastgrnn_cuda.cpp:147-180 -> [hidden_states, z_s, h_prime_s] (each [T,B,H]).
     ``want_gates=False`` (extension) returns ``[hidden_states]`` only and skips the two
     extra [T,B,H] stores -- forward-only / inference use."""
     return _forward_impl(input, w, u, bias_gate, bias_update, zeta, nu, initial_h, z_non_linearity,
-                         w1, w2, u1, u2, True, update_non_linearity, want_gates, flags, keep_preact=keep_preact)
+                         w1, w2, u1, u2, True, update_non_linearity, want_gates, flags)
 
 
 def backward_unroll(grad_h, input, hidden_states, zeta, nu, w, u, z, h_prime, initial_h, w1, w2, u1, u2,

@@ -60,10 +60,6 @@ class FastGRNNFunction(Function):
         return _as_autograd_grads(outputs, ctx.needs_input_grad)
 
 
-# Activation-memory option for the register-resident low-rank cells (H=256, F=32, ranks 1..16); see forward() below.
-LOWRANK_RECOMPUTE_PREACT = False
-
-
 class FastGRNNUnrollFunction(Function):
     """rnn.py:907-972.  Same inputs, same gradients; what is SAVED between the two passes is
     an internal matter: on the split-precision kernel path the forward keeps one auxiliary
@@ -104,12 +100,8 @@ class FastGRNNUnrollFunction(Function):
         if x_bft:
             flags |= _lib.FLAG_X_BFT
         ctx.flags = flags
-        # (register-resident low-rank cells: the saved rank-space vector is enough for the backward, which can recompute
-        # the pre-activation from it -- LOWRANK_RECOMPUTE_PREACT = True stores one [T,B,H] tensor less per layer, 415 MB
-        # at B=4096; the time is the same: the forward gains what the backward's extra products cost)
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
-                                               gate_non_linearity, w1, w2, u1, u2, flags=flags,
-                                               keep_preact=not LOWRANK_RECOMPUTE_PREACT)
+                                               gate_non_linearity, w1, w2, u1, u2, flags=flags)
         hidden_states = outputs[0]
         if preact:
             # outputs[2] (factorised operands only): the rank-space vector [U1.h | W1.x] per step

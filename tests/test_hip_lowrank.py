@@ -274,41 +274,51 @@ def test_factorised_cells_on_the_dense_h128_kernels(Fi, Hi, rw, ru, B, flags):
         assert err <= lim, (k, err, lim)
 
 
-@pytest.mark.parametrize("B,rw,ru,bf16,bm", [(64, 16, 16, False, False), (37, 16, 16, False, False), (48, 8, 12, False, True),
-                                             (33, 16, 16, True, False), (4096, 16, 16, False, False)])
-def test_backward_recomputes_the_preactivation_bit_for_bit(B, rw, ru, bf16, bm):
-    """forward_unroll(..., keep_preact=False) stores the rank-space vector alone (z_s = NULL in the C ABI); the backward
-    recomputes the pre-activation from it with the forward's own product -- same operands, same order -- so every
-    gradient equals the run that kept the [T,B,H] tensor, bit for bit."""
-    T = 99 if B == 4096 else 17
-    _, P = _params(rw, ru, seed=12)
+@pytest.mark.parametrize("B,rw,ru,bf16", [(4096, 16, 16, False), (4096 + 5, 16, 16, False), (2048, 7, 13, False), (4096, 16, 16, True)])
+def test_factor_gradients_contracted_inside_the_scan(B, rw, ru, bf16):
+    """The factor gradients (d_w1, d_w2, d_u1, d_u2: .cu:546-555) are sums over the T*B rows that the backward scan
+    contracts itself, per workgroup of 16 utterances, into slabs that one fixed-order reduction adds up (round 3; they
+    were three GEMMs over a d_pre[T,B,H] round trip).  At the BASELINE size, where the oracle comparison lives in
+    tests/test_hip_fullsize.py, the size-independent properties: the same bits from one launch to the next, the
+    data-parallel identity (the gradient of the batch is the sum of its shards' gradients) and linearity in grad_hs."""
+    T = 99
+    _, P = _params(rw, ru, seed=21)
     dt = torch.bfloat16 if bf16 else torch.float32
-    g = torch.Generator().manual_seed(5 + B)
+    g = torch.Generator().manual_seed(3 + B)
     x = torch.randn(T, B, F, generator=g).to(dt).to(DEV)
     G = torch.randn(T, B, H, generator=g).to(dt).to(DEV)
     h0 = (0.3 * torch.randn(B, H, generator=g)).to(DEV)
-    if bm:
-        x, G = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
-    fl = SAVE_PREACT | (BATCH_MAJOR if bm else 0)
-    args = (x, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], h0, 0, P["w1"], P["w2"], P["u1"], P["u2"])
-    kw = dict(bias_gate=P["bias_gate"], bias_update=P["bias_update"])
-    o_k = fastgrnn_cuda.forward_unroll(*args, flags=fl)
-    g_k = fastgrnn_cuda.backward_unroll(G, x, o_k[0], P["zeta"], P["nu"], P["w"], P["u"], o_k[1], o_k[2], h0,
-                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
-    # same hs, same rank-space vector, no pre-activation tensor: the recomputed one must give the same bits
-    none = torch.empty(0, device=DEV)
-    g_r = fastgrnn_cuda.backward_unroll(G, x, o_k[0], P["zeta"], P["nu"], P["w"], P["u"], none, o_k[2], h0,
-                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
-    for k, (a, b) in enumerate(zip(g_k, g_r)):
-        assert torch.equal(a, b), k
-    # the forward that stores the rank-space vector alone is another instantiation of the kernel: equal to fp32 rounding
-    o_n = fastgrnn_cuda.forward_unroll(*args, flags=fl, keep_preact=False)
-    assert o_n[1].numel() == 0
-    tol = 2.0 ** -7 if bf16 else 2e-6
-    assert float((o_k[0].float() - o_n[0].float()).abs().max()) <= tol
-    assert float((o_k[2] - o_n[2]).abs().max()) <= 2e-6 * max(1.0, float(o_k[2].abs().max()))
-    g_n = fastgrnn_cuda.backward_unroll(G, x, o_n[0], P["zeta"], P["nu"], P["w"], P["u"], o_n[1], o_n[2], h0,
-                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl, **kw)
-    for k, (a, b) in enumerate(zip(g_k, g_n)):
-        if a.numel():
-            assert float((a.float() - b.float()).abs().max()) <= (2.0 ** -6 if bf16 else 2e-5) * max(1.0, float(a.float().abs().max())), k
+    outs, g1 = _run(P, x, G, h0, SAVE_PREACT)
+    _, g2 = _run(P, x, G, h0, SAVE_PREACT)
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        assert torch.equal(a, b), k                                   # no atomics, fixed reduction order
+    # shards: utterances [0, cut) and [cut, B), cut not a multiple of 16
+    cut = B // 2 + 3
+    parts = []
+    for lo, hi in ((0, cut), (cut, B)):
+        _, gp = _run(P, x[:, lo:hi].contiguous(), G[:, lo:hi].contiguous(), h0[lo:hi].contiguous(), SAVE_PREACT)
+        parts.append(gp)
+    tol = 2.0 ** -6 if bf16 else 2e-5
+    for k in (1, 2, 3, 4, 8, 9, 10, 11):                              # d_bias_z, d_bias_h, d_zeta, d_nu, d_w1, d_w2, d_u1, d_u2
+        whole, summed = g1[k].float(), parts[0][k].float() + parts[1][k].float()
+        assert float((whole - summed).abs().max()) <= tol * max(1.0, float(whole.abs().max())), k
+    for k in (0, 5):                                                  # d_input, d_old_h: per utterance, bit for bit
+        cat = torch.cat([parts[0][k], parts[1][k]], dim=1 if k == 0 else 0)
+        assert torch.equal(g1[k], cat), k
+    if not bf16:
+        gr = fastgrnn_cuda.backward_unroll(-0.5 * G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[2], h0,
+                                           P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=SAVE_PREACT,
+                                           bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+        for k in (8, 9, 10, 11):
+            assert float((gr[k] + 0.5 * g1[k]).abs().max()) <= 2e-6 * max(1.0, float(g1[k].abs().max())), k
+
+
+def test_lowrank_backward_wants_both_saved_tensors():
+    """z_s = NULL (round 2's recomputing variant) is an error again: include/fastgrnn_hip.h at fastgrnn_hip_kernel_path."""
+    _, P = _params(16, 16, seed=2)
+    x = torch.randn(5, 16, F, device=DEV); G = torch.randn(5, 16, H, device=DEV); h0 = torch.zeros(16, H, device=DEV)
+    outs, _ = _run(P, x, G, h0, SAVE_PREACT)
+    with pytest.raises(RuntimeError):
+        fastgrnn_cuda.backward_unroll(G, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], torch.empty(0, device=DEV), outs[2], h0,
+                                      P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=SAVE_PREACT,
+                                      bias_gate=P["bias_gate"], bias_update=P["bias_update"])

@@ -47,13 +47,15 @@ def _oracle(x, G, p, h0, gate="sigmoid"):
 
 
 # d_zeta / d_nu are ONE scalar each: sums of T*B*H terms of either sign that cancel to a result 1e2..1e4 times smaller
-# than the sum of their magnitudes.  Their error is therefore bounded relative to that sum of magnitudes (which the
-# oracle reports): 2e-7 of it, i.e. every term good to about three fp32 roundings -- on top of the common 2e-5 of the
-# result, which the BASELINE configurations meet on their own (tests/test_hip_fullsize.py).
+# than the sum of their magnitudes.  scalar_term_tol > 0 bounds their error relative to that sum of magnitudes (which the
+# oracle reports) as well -- 2e-7 of it, i.e. every term good to about three fp32 roundings.  Round 2 applied that to
+# every layer shape, because the dense H=256 backward needed it (4-5.5e-5 of the result); since round 3 its chain carries
+# d_pre exactly and H=256 is held to the plain 2e-5.  What still takes the conditioning-aware bound is the wide-input
+# layer at full size (d_nu 2.5e-5 of a result that is 1e-4 of its terms' magnitudes).
 SCALAR_TERM_TOL = 2e-7
 
 
-def _check(gr, g_o, tol=2e-5):
+def _check(gr, g_o, tol=2e-5, scalar_term_tol=0.0):
     errs = {}
     bad = {}
     for n, o in zip(NAMES, gr[:8]):
@@ -61,8 +63,8 @@ def _check(gr, g_o, tol=2e-5):
         abs_err = float(np.abs(o.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max())
         errs[n] = abs_err / max(1.0, float(np.abs(ref).max()))
         lim = tol * max(1.0, float(np.abs(ref).max()))
-        if n in ("d_zeta", "d_nu") and ("_abs_" + n[2:]) in g_o:
-            lim = max(lim, SCALAR_TERM_TOL * g_o["_abs_" + n[2:]])
+        if scalar_term_tol and n in ("d_zeta", "d_nu") and ("_abs_" + n[2:]) in g_o:
+            lim = max(lim, scalar_term_tol * g_o["_abs_" + n[2:]])
         if abs_err > lim:
             bad[n] = errs[n]
     assert not bad, (bad, errs)
@@ -186,7 +188,7 @@ def test_stack_layer_full_batch_every_output_vs_fp64_oracle(F, H):
     outs, gr = _run(_t(x), _t(h0), _t(G), p, preact=True)
     hs_o, zs_o, cs_o, g_o = _oracle(x, G, p, h0)
     assert np.abs(outs[0].cpu().numpy() - hs_o).max() <= 1e-5
-    errs = _check(gr, g_o)
+    errs = _check(gr, g_o, scalar_term_tol=SCALAR_TERM_TOL if H == 128 else 0.0)   # (H = 256: plain 2e-5)
     print("stack layer F=%d H=%d full-size errors: %s" % (F, H, {k: "%.2e" % v for k, v in errs.items()}))
 
 
@@ -260,12 +262,12 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
     rel = lambda a, ref: float(np.abs(a.detach().cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()) / max(1e-3, float(np.abs(ref).max()))
     # the loss is a MEAN over 4096 utterances: gradients are ~1e-4 in size, so they are compared relative to their
     # own largest element (floor 1e-3), at the 2e-5 the single layers meet
-    assert rel(xt.grad, dx_o) <= 5e-5
+    assert rel(xt.grad, dx_o) <= 2e-5
     assert rel(m.hidden2keyword.weight.grad, dw_o) <= 2e-5 and rel(m.hidden2keyword.bias.grad, db_o) <= 2e-5
     for rnn, go in zip(m.rnn_list, grads_o):
         for name, par in (("d_w", rnn.W), ("d_u", rnn.U), ("d_bias_gate", rnn.bias_gate), ("d_bias_update", rnn.bias_update),
                           ("d_zeta", rnn.zeta), ("d_nu", rnn.nu)):
-            assert rel(par.grad, go[name]) <= 5e-5, (name, rel(par.grad, go[name]))
+            assert rel(par.grad, go[name]) <= 2e-5, (name, rel(par.grad, go[name]))
     with torch.no_grad():
         m.init_hidden()
         scores = m(_t(x))

@@ -110,9 +110,11 @@ def test_unusual_inputs_against_the_oracle(family, scenario):
             lim = max(lim, 2e-7 * g_o["_abs_" + k[2:]])
         lim = max(lim, 1e-6 * gscale)
         if ill:
-            # (the H=256 backward's fp16 two-plane chain carries 22 bits: on an expansive recurrence its error grows
-            # to several times that of an fp32 evaluation -- d_nu 4.5e-4 here against 8e-5 -- DESIGN.md 4.1c)
-            fac = 12.0 if H == 256 and r != 16 else 3.0
+            # (three times what the same formulas evaluated in fp32 are off by.  The dense H=256 backward gets six: its
+            # chain carries d_pre exactly since round 3, but U^T as two fp16 planes, 22 bits -- a FIXED relative
+            # perturbation of the weights of 2^-23 that an expansive recurrence amplifies step after step the same way,
+            # where independent roundings average out: d_nu 4.5e-4 here against 8e-5, DESIGN.md 4.1c.  It was twelve.)
+            fac = 6.0 if H == 256 and r != 16 else 3.0
             lim = max(lim, fac * float(np.abs(g_32[k].reshape(v.shape) - v).max()))
         if scenario == "zero_grad":
             assert err == 0.0, (k, err)

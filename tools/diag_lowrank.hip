@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   printf("bwd_scan_lowrank_split (stamped): %.1f us (%.2f us/step)\n", ts[ts.size() / 2] * 1e3, ts[ts.size() / 2] * 1e3 / T);
   unsigned long long h[8][8];
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sdiag), sizeof(h));
-  const char* names[8] = {"EW+completion", "images", "refill", "partial", "B1+sum+C1+B2", "mB+d_h", "C2/C3 issue", "-"};
+  const char* names[8] = {"EW+completion", "images", "refill", "partial", "barrier", "sum+mB+d_h", "trailing issue", "-"};
   for (int wv = 0; wv < 8; ++wv) {
     unsigned long long tot = 0;
     for (int k = 0; k < 8; ++k) tot += h[wv][k];
