@@ -132,4 +132,22 @@ int head_xent(int B, int H, int C, const void* h_last, const void* fc_w, const v
 // test hook (kernels_debug.hip): fill every CU's LDS and vector registers with a bit pattern
 int debug_poison(unsigned pattern, hipStream_t s);
 
+namespace {
+// Completion read (operand rule): ONE vector instruction the compiler cannot drop reads `v` -- an
+// element of the youngest accumulator, or a sum of several: MFMAs retire in order, so once it has executed every MFMA
+// issued before it has read its operands.  v_readfirstlane into a scalar register that an empty asm consumes: no
+// branch, no memory instruction (the first form, `if (v == <never>) <store>`, put a conditional store into scan loops:
+// second rule of 4.0).
+__device__ __forceinline__ void completion_read(float v) {
+  const int s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v));
+  asm volatile("" :: "s"(s));
+}
+
+// Second rule of DESIGN.md 4.0, by construction: no LDS write is pending when a conditional branch -- exec-masked or
+// wave-uniform -- with a vector-memory instruction behind it is taken.  Placed in front of such regions where LDS
+// writes precede them in the same loop iteration without a barrier in between.
+__device__ __forceinline__ void lds_writes_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+}  // namespace
+
 }  // namespace fastgrnn

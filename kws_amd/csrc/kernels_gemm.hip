@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
         float touch = 0.f;                         // every accumulator of the batch has retired before Bf is reloaded
 #pragma unroll
         for (int a = 0; a < NPW; ++a) touch += hi[a][0] + lo[a][0];
-        if (touch == 1.2345678e38f) pl[0][0][0] = 1;
+        completion_read(touch);
         __builtin_amdgcn_sched_barrier(0);
       }
       const size_t r = r0 + rt * 16 + i;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
         for (int c = 0; c < NBATCH; ++c)
 #pragma unroll
           for (int a = 0; a < MA; ++a) touch += acc[a][c0 + c][0];
-        if (touch == 1.2345678e38f) part[0] = 1.f;
+        completion_read(touch);
         __builtin_amdgcn_sched_barrier(0);
         SPLIT_STAMP(2)
       }

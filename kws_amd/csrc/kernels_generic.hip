@@ -47,6 +47,7 @@ __global__ __launch_bounds__(NTHREADS) void fwd_scan_generic(
   for (int i = tid; i < BT * H; i += nth) {
     int b = i / H;
     hbuf[i] = (b0 + b < B) ? h0[(size_t)(b0 + b) * H + (i % H)] : T(0);
+    lds_writes_landed();
   }
   int cur = 0;
   for (int t = 0; t < Tn; ++t) {
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(NTHREADS) void fwd_scan_generic(
     for (int i = tid; i < BT * F; i += nth) {
       int b = i / F;
       xs[i] = (b0 + b < B) ? x[((size_t)t * B + b0 + b) * F + (i % F)] : T(0);
+      lds_writes_landed();                         // (second rule of DESIGN.md 4.0: see fwd below)
     }
     __syncthreads();
     if (rw) {
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(NTHREADS) void fwd_scan_generic(
         T a = 0;
         for (int f = 0; f < F; ++f) a += xs[b * F + f] * w1[(size_t)j * F + f];
         mx[i] = a;
+        lds_writes_landed();
       }
     }
     if (ru) {
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(NTHREADS) void fwd_scan_generic(
         T a = 0;
         for (int k = 0; k < H; ++k) a += hc[b * H + k] * u1[(size_t)j * H + k];
         mh[i] = a;
+        lds_writes_landed();
       }
     }
     if (rw || ru) __syncthreads();
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void bwd_scan_generic(
         T a = 0;
         for (int n = 0; n < H; ++n) a += dp[b * H + n] * u2[(size_t)n * ru + j];
         dmh[i] = a;
+        lds_writes_landed();
       }
       __syncthreads();
       for (int k = tid; k < H; k += nth) {
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(NTHREADS) void bwd_scan_generic(
         }
 #pragma unroll
         for (int b = 0; b < BT; ++b) dh[b * H + k] += acc[b];
+        lds_writes_landed();
       }
     } else {
       for (int k = tid; k < H; k += nth) {
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(NTHREADS) void bwd_scan_generic(
         }
 #pragma unroll
         for (int b = 0; b < BT; ++b) dh[b * H + k] += acc[b];
+        lds_writes_landed();
       }
     }
     __syncthreads();
@@ -303,8 +310,11 @@ __global__ __launch_bounds__(256) void gemm_tn_splitk(size_t R, int M, int N, si
   T acc = 0;
   for (size_t r = r0; r < r1; r += 16) {
     size_t rr = r + ty;
-    As[ty][tx] = (rr < r1 && m0 + tx < M) ? A[rr * lda + m0 + tx] : T(0);
-    Bs[ty][tx] = (rr < r1 && n0 + tx < N) ? row_ptr<T>(B0, B1, shiftB, rr, ldb)[n0 + tx] : T(0);
+    // (both predicated loads first, then the LDS writes: second rule of DESIGN.md 4.0)
+    const T av = (rr < r1 && m0 + tx < M) ? A[rr * lda + m0 + tx] : T(0);
+    const T bv = (rr < r1 && n0 + tx < N) ? row_ptr<T>(B0, B1, shiftB, rr, ldb)[n0 + tx] : T(0);
+    As[ty][tx] = av;
+    Bs[ty][tx] = bv;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc += As[k][ty] * Bs[k][tx];
@@ -370,12 +380,14 @@ __global__ __launch_bounds__(256) void gemm_rows_tiled(size_t M, int N, int K, c
       const int rr = idx / KC, kk = idx % KC;
       const size_t m = m0 + rr;
       As[rr][kk] = (m < M && k0 + kk < K) ? row_ptr<T>(A0, A1, shiftA, m, K)[k0 + kk] : T(0);
+      lds_writes_landed();                       // (second rule of DESIGN.md 4.0: the next iteration's predicated load)
     }
     for (int idx = tid; idx < KC * 64; idx += 256) {
       const int kk = idx / 64, n = idx % 64;
       T v = 0;
       if (n < N && k0 + kk < K) v = transB ? Bm[(size_t)n * K + k0 + kk] : Bm[(size_t)(k0 + kk) * N + n];
       Bs[kk][n] = v;
+      lds_writes_landed();
     }
     __syncthreads();
 #pragma unroll 8

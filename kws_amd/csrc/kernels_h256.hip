@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       float touch = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) touch += a[mt][0] + alo[mt][0];
-      if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
+      completion_read(touch);
       if (H16) {                                     // fp16 path: W.x is complete; one sum instead of two accumulators
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) a[mt] += alo[mt];
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       float touch = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) touch += H16 ? (ah[mt][0] + ahl[mt][0]) : (a[mt][0] + alo[mt][0]);
-      if (touch == 1.2345678e38f) sbias[0][0] = 1.f;   // (never true; sbias is read, so the compare cannot be dropped)
+      completion_read(touch);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: .cu:55-58 -----------------------------------------------------------------------------

@@ -54,10 +54,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
   for (int e = tid; e < HEAD_UTT * H; e += HEAD_THREADS) {
     const int u = e / H, n = e - u * H;
     sh[u * HP + n] = (u < nu) ? h_last[(size_t)(b0 + u) * H + n] : 0.f;
+    lds_writes_landed();                           // (second rule of DESIGN.md 4.0: the next iteration's load)
   }
   for (int e = tid; e < C * H; e += HEAD_THREADS) {
     const int c = e / H, n = e - c * H;
     sw[c * HP + n] = fc_w[e];
+    lds_writes_landed();                           // (second rule of DESIGN.md 4.0: the next iteration's load)
   }
   __syncthreads();
   // ---- logits[u][c] = b[c] + W[c,:] . h[u,:]            (model.py:227)
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
     const float* wp = sw + c * HP;
     for (int n = 0; n < H; ++n) acc = fmaf(wp[n], hp[n], acc);
     sdl[u * CP + c] = acc;
+    lds_writes_landed();                           // (second rule of DESIGN.md 4.0: the next iteration's load)
   }
   __syncthreads();
   // ---- per utterance: log_softmax (model.py:229), NLL term and d_logits = (softmax - onehot) / B
@@ -89,9 +92,10 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_xent_fwd_bwd(
         if (logp) logp[(size_t)(b0 + u) * C + c] = lp;
         if (c == (int)y) l = -lp;                                       // trainClassifier.py:236
         row[c] = ignored ? 0.f : (expf(lp) - (c == (int)y ? 1.f : 0.f)) * inv_B;
+        lds_writes_landed();                       // (the next class's conditional logp store)
       }
     } else {
-      for (int c = 0; c < C; ++c) row[c] = 0.f;
+      for (int c = 0; c < C; ++c) { row[c] = 0.f; lds_writes_landed(); }
     }
     sloss[u] = l;
   }

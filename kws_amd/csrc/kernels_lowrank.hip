@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
                    "v"(Ahp[0].p[0]), "v"(Ahp[0].p[1]), "v"(Ahp[0].p[2]), "v"(Ahp[1].p[0]), "v"(Ahp[1].p[1]), "v"(Ahp[1].p[2]),
                    "v"(Bdm.p[0]), "v"(Bdm.p[1]), "v"(Bdm.p[2]), "v"(Ax.p[0]), "v"(Ax.p[1]), "v"(Ax.p[2]),
                    "v"(Bdmx.p[0]), "v"(Bdmx.p[1]), "v"(Bdmx.p[2]));
-    if (tie == 1.2345678e38f) red[0] = 1.f;
+    completion_read(tie);
     __builtin_amdgcn_sched_barrier(0);
   };
   // The factor-gradient products of a step (.cu:546-555): d_u2 | d_w2 += d_pre^T . [m_h | m_x], d_w1^T += x^T . d_m_x,
@@ -536,14 +536,18 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     SPLIT_STAMP(0)
     // ---- planes of d_pre_t (B operand of the rank-space partial as they are; transposed, the A operand of the
     //      d_u2|d_w2 products) and of h_{t-1} through the private image; one value each of m_t and x_t into the shared ones
-    if (t > 0) { load_ew_ga(t - 1, e, 0); load_ew_ga(t - 1, e, 1); }   // (EW(t) has consumed them; the previous step's MFMAs have retired)
+    // (EW(t) has consumed them; the previous step's MFMAs have retired.  No branch around any of the refills: step 0
+    // re-requests its own operands -- second rule of DESIGN.md 4.0, these requests follow LDS writes)
+    const int tn = t > 0 ? t - 1 : 0;
+    load_ew_ga(tn, e, 0); load_ew_ga(tn, e, 1);
     __builtin_amdgcn_sched_barrier(0);
     const Frag3 dfr = split3(dpv[0], dpv[1]);
     put_img(dfr);
     tr_half(0, Adp[0]); tr_half(1, Adp[1]);
     put_img(split3(e.h[0], e.h[1]));                 // (stays in the image until the products behind the barrier want it)
     __builtin_amdgcn_sched_barrier(0);
-    if (t > 0) load_ew_h(t - 1, e);
+    if (BF) lds_writes_landed();                     // (bf16 sequences: the fp32 h0 of step 0 is a branch of its own)
+    load_ew_h(tn, e);
     __builtin_amdgcn_sched_barrier(0);
     {
       unsigned char* const so = my_s + cur * (6 * IMG_PLANE);
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     load_uw2t(UW2Tf);
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
-    if (t > 0) load_ew_mx(t - 1, e);
+    load_ew_mx(tn, e);
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(2)
     // ---- rank-space partial over own units: B operand = this lane's fragment of d_pre ----

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float touch = 0.f;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) touch += dh[mt][0];
-      if (touch == 1.2345678e38f) S.DX[0][0][0][0][0] = 1.f;
+      completion_read(touch);
       __builtin_amdgcn_sched_barrier(0);
     }
     // Operands of EW(t-2) and of dW(t-1) are requested here, a whole iteration before their use (eo / xo were
@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // through the chain's shadow (as this kernel first had them) the compiler lands them in the chain's own B
     // registers as those die, right behind the MFMAs that read them.  Now those registers are
     // free for them, and the four regions below cover the latency.
+    lds_writes_landed();                   // (second rule of DESIGN.md 4.0: conditional requests and stores follow)
     if (!LAST) {
       load_xt(t - 1, x_load);
       load_ew(t >= 2 ? t - 2 : 0, e_load);
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int c2 = 0; c2 < NCT; ++c2) touch += accU[a2][c2][0];
         }
-        if (touch == 1.2345678e38f) S.DX[0][0][0][0][0] = 1.f;
+        completion_read(touch);
         __builtin_amdgcn_sched_barrier(0);
       }
     }

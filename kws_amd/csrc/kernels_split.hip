@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void fwd_scan_split(
       keep_alive(probe, xB);
 #pragma unroll
       for (int s = 0; s < KS; ++s) keep_alive(probe, hB[s]);
-      if (probe == 1.2345678e38f) hown[0][0] = 0.f;
+      completion_read(probe);
       __builtin_amdgcn_sched_barrier(0);
     }
     tile_epilogue(1, acc1);
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
   };
   auto store_step = [&](int t, const f32x4 aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
+    if (RAGGED) lds_writes_landed();                  // (an exec-masked store block: no LDS write pending in front of it)
     if (valid) {
       const size_t o = hs_last ? (size_t)b * H + n0 : ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
       if (BF) st4_bf16(reinterpret_cast<unsigned short*>(hs) + o, hown); else st4(hs + o, hown);
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
       hown[r] = (sz * (1.0f - z) + sn) * c + hown[r] * z;
       zq[r] = z; cq[r] = c;
     }
+    if (AUX == 1 && RAGGED) lds_writes_landed();
     if (AUX == 1 && valid) {                          // reference operator outputs: stored at once
       const size_t o = ((size_t)t * rsT + (size_t)b * rsB) * H + n0;
       st4(zs + o, zq); st4(cs + o, cq);
@@ -627,8 +629,12 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
                                  : reinterpret_cast<const char*>(hs) + (step_h - (size_t)rsT * H) * ESZ;   // .cu:478-481
     const char* xbase = xbft ? reinterpret_cast<const char*>(x) + (size_t)t * ESZ
                              : reinterpret_cast<const char*>(x) + (size_t)t * rsT * F * ESZ;
+    // (the gradient is requested unconditionally and replaced by zeros where it does not apply: a load inside the
+    // conditional would put a wave-uniform branch between the step's LDS plane writes and these requests -- DESIGN.md
+    // 4.0, second rule)
     if (BF) {                                        // h0 and the saved tensor are fp32; EW(0) fetches h0 itself
-      e.graw = g_zero ? uint2{0u, 0u} : ldg2(gbase, goff);
+      const uint2 graw = ldg2(gbase, goff);
+      e.graw = g_zero ? uint2{0u, 0u} : graw;
       if (RAGGED && !valid) e.graw = uint2{0u, 0u};
       e.hraw = ldg2(hbase, lane_e * ESZ);            // (t == 0: a dummy row of hs; h0 below is what EW(0) uses)
       // h_prev of step 0 is the fp32 h0: requested HERE, with the step's other operands (load_ew runs behind a
@@ -636,7 +642,8 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       if (t == 0) e.h = ldg4(h0, lane_bh * 4u);
       if (!NOX) e.xraw = *reinterpret_cast<const unsigned short*>(xbase + lane_x * ESZ);
     } else {
-      e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : ldg4(gbase, goff);
+      const f32x4 gv = ldg4(gbase, goff);
+      e.g = g_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : gv;
       // Lanes beyond a ragged batch re-read the last utterance's (finite) rows with a ZERO gradient: with dh = 0
       // at the start, gg, d_pre and every sum they enter stay exactly zero for them -- nothing else to mask.
       if (RAGGED && !valid) e.g = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
       float touch = 0.f;                       // one element of every accumulator of the batch: all have retired
 #pragma unroll
       for (int c = 0; c < NB; ++c) touch += acc[0][C0 + c][0] + acc[1][C0 + c][0];
-      if (touch == 1.2345678e38f) S.red[15] = 1.f;
+      completion_read(touch);
       __builtin_amdgcn_sched_barrier(0);
     };
     // batches of 2 + 2 + 1 column tiles: with 3 + 2 the kernel spilled nine registers inside the loop
@@ -855,7 +862,9 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     if constexpr (!LAST) {
       ew_post(t - 1, eo, f, eo.g + dh);
       __builtin_amdgcn_sched_barrier(0);
-      // requests for EW(t-2), after the chain has retired (they may land in registers its fragments used)
+      // requests for EW(t-2), after the chain has retired (they may land in registers its fragments used).  bf16
+      // sequences: the request for the fp32 h0 sits in a wave-uniform branch -- the plane writes above have landed first
+      if (BF) lds_writes_landed();
       load_ew(t >= 2 ? t - 2 : 0, eo);
     }
     __builtin_amdgcn_sched_barrier(0);

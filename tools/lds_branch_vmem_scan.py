@@ -53,7 +53,67 @@ def vregs(tok):
     return out
 
 
+def scc(succ):
+    """component id per node for nodes on a cycle (Tarjan, iterative); -1 for the others"""
+    n = len(succ)
+    index = [None] * n
+    low = [0] * n
+    on = [False] * n
+    comp = [-1] * n
+    stack, counter, ncomp = [], 0, 0
+    for root in range(n):
+        if index[root] is not None:
+            continue
+        work = [(root, 0)]
+        while work:
+            v, pi = work.pop()
+            if pi == 0:
+                index[v] = low[v] = counter
+                counter += 1
+                stack.append(v)
+                on[v] = True
+            recurse = False
+            for qi in range(pi, len(succ[v])):
+                w = succ[v][qi]
+                if w >= n:
+                    continue
+                if index[w] is None:
+                    work.append((v, qi + 1))
+                    work.append((w, 0))
+                    recurse = True
+                    break
+                if on[w]:
+                    low[v] = min(low[v], index[w])
+            if recurse:
+                continue
+            if low[v] == index[v]:
+                members = []
+                while True:
+                    w = stack.pop()
+                    on[w] = False
+                    members.append(w)
+                    if w == v:
+                        break
+                if len(members) > 1 or v in succ[v]:
+                    for w in members:
+                        comp[w] = ncomp
+                    ncomp += 1
+            if work:
+                u = work[-1][0]
+                low[u] = min(low[u], low[v])
+    return comp
+
+
 NARROW = "--narrow" in sys.argv      # only: LDS WRITE whose data registers a VALU instruction behind the branch overwrites
+WRITES = "--writes" in sys.argv      # any LDS WRITE in front of the branch (whatever happens to its data registers behind it)
+# --strict: --writes with NO window in front of the branch: the look-back runs to the nearest `s_waitcnt lgkmcnt(0)`,
+# barrier or label (a label = a join: another path may arrive there with its own pending writes, so the walk
+# continues above it only if everything in between is fall-through code).  This is the form tests/test_operand_rule_cpu.py
+# requires to be empty in every kernel of the library since round 3: an LDS write may never be pending when a conditional
+# branch -- exec-masked or wave-uniform -- with a vector-memory instruction behind it is taken.
+STRICT = "--strict" in sys.argv
+if STRICT:
+    WRITES = True
 total = 0
 for name, body in kernels(path):
     labels = {}
@@ -71,24 +131,84 @@ for name, body in kernels(path):
         if m and m.group(1) in labels and labels[m.group(1)] <= j:
             loops.append((labels[m.group(1)], j))
     hits = []
+    if STRICT:
+        # control-flow graph of the kernel: successors / predecessors by instruction index
+        n = len(ins)
+        succ = [[] for _ in range(n)]
+        for j, t in enumerate(ins):
+            m = re.match(r"s_(c?)branch\w*\s+(\.L\w+)", t)
+            if t.startswith("s_endpgm"):
+                continue
+            if m and m.group(2) in labels:
+                succ[j].append(labels[m.group(2)])
+                if m.group(1) and j + 1 < n:
+                    succ[j].append(j + 1)
+            elif j + 1 < n:
+                succ[j].append(j + 1)
+        pred = [[] for _ in range(n)]
+        for j in range(n):
+            for k in succ[j]:
+                if k < n:
+                    pred[k].append(j)
+        # loops = strongly connected components of the graph (a backward jump alone is not one: the compiler parks
+        # blocks behind the kernel's end and jumps back from them)
+        comp = scc(succ)
+        for j, t in enumerate(ins):
+            if not t.startswith("s_cbranch"):
+                continue
+            if comp[j] < 0:
+                continue
+            # a vector-memory instruction within W instructions behind the branch, along either arm
+            vm, seen, front = None, set(), [(k, 1) for k in succ[j]]
+            while front and vm is None:
+                k, d = front.pop()
+                if k in seen or k >= n or d > W:
+                    continue
+                seen.add(k)
+                if ins[k].startswith(VMEM):
+                    vm = ins[k]
+                    break
+                front.extend((q, d + 1) for q in succ[k])
+            if vm is None:
+                continue
+            # an LDS write on some path to the branch with no `s_waitcnt lgkmcnt(0)` / barrier behind it (paths are
+            # followed backwards inside the loop; its entry from outside ends a path)
+            lds, seen, front = None, set(), list(pred[j])
+            while front and lds is None:
+                k = front.pop()
+                if k in seen or comp[k] != comp[j]:
+                    continue
+                seen.add(k)
+                u = ins[k]
+                if u.startswith("s_barrier") or (u.startswith("s_waitcnt") and "lgkmcnt(0)" in u):
+                    continue
+                if u.startswith(("ds_write", "ds_store", "ds_add", "ds_max", "ds_min")):
+                    lds = u
+                    break
+                front.extend(pred[k])
+            if lds:
+                hits.append((lds.split()[0], t.split()[0], vm.split()[0]))
     for j, t in enumerate(ins):
+        if STRICT:
+            break
         if not t.startswith("s_cbranch"):
             continue
         if not any(a <= j <= b for a, b in loops):
             continue
+        loop_lo = max(a for a, b in loops if a <= j <= b)        # innermost enclosing loop's first instruction
         lds = None
         data = set()
-        for k in range(j - 1, max(-1, j - 1 - W), -1):
+        for k in range(j - 1, (loop_lo - 1) if STRICT else max(-1, j - 1 - W), -1):
             u = ins[k]
             if u.startswith("s_barrier") or (u.startswith("s_waitcnt") and "lgkmcnt(0)" in u):
                 break
-            if u.startswith("ds_") and (not NARROW or u.startswith(("ds_write", "ds_store"))):
+            if u.startswith("ds_") and (not (NARROW or WRITES) or u.startswith(("ds_write", "ds_store", "ds_add", "ds_max", "ds_min"))):
                 if lds is None:
                     lds = u
                 ops = u.split(None, 1)[1].split(",") if " " in u else []
                 for o in ops[1:]:
                     data |= vregs(o)
-                if not NARROW:
+                if not (NARROW or WRITES):
                     break
         if lds is None:
             continue
