@@ -68,7 +68,8 @@ def _time_steps(step, warmup, blocks, steps_per_block):
 
 def extra_configs(dev, B):
     """The other BASELINE.json configurations on one GPU (same synthetic data shapes): each entry carries ms_per_step
-    (median of 10 blocks of 5 steps), utterances/s, the algorithmic bytes of SURVEY 8(d) and the fraction of the HBM
+    (median of 10 blocks of 20 steps enqueued back to back: a block starts on an idle queue, and with 5-step blocks that
+    start was a fifth of what the fwd-only line reported), utterances/s, the algorithmic bytes of SURVEY 8(d) and the fraction of the HBM
     roof they amount to, plus fp32-equivalent FLOP/s against the fp32 MFMA peak."""
     from kws_amd import FastGRNNCUDA, RNNClassifierModel, fastgrnn_cuda
     res = {}
@@ -90,7 +91,7 @@ def extra_configs(dev, B):
     def fwd_only():
         with torch.no_grad():
             m(x)
-    res["fwd_only_f32"] = entry(_time_steps(fwd_only, 3, 10, 5), B * BYTES_FWD, B * FLOPS_FWD,
+    res["fwd_only_f32"] = entry(_time_steps(fwd_only, 5, 10, 20), B * BYTES_FWD, B * FLOPS_FWD,
                                 "dense fwd-only, F=32 H=128 T=99 B=%d fp32 (BASELINE config 2)" % B,
                                 {"forward": fastgrnn_cuda.kernel_path(T, B, F, H, direction=0)})
     # config 3: bf16 sequences, fp32 master gradients
@@ -101,7 +102,7 @@ def extra_configs(dev, B):
         for p_ in params:
             p_.grad = None
         m(xb).backward(Gb)
-    res["fwd_bwd_bf16"] = entry(_time_steps(step_bf16, 3, 10, 5), B * (BYTES_FWD + BYTES_BWD) // 2, B * (FLOPS_FWD + FLOPS_BWD),
+    res["fwd_bwd_bf16"] = entry(_time_steps(step_bf16, 5, 10, 20), B * (BYTES_FWD + BYTES_BWD) // 2, B * (FLOPS_FWD + FLOPS_BWD),
                                 "dense fwd+bwd, bf16 x/hs/grad_hs/d_x, fp32 state + master gradients (BASELINE config 3)",
                                 {"forward": fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=0, flags=4),
                                  "backward": fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=1, flags=4)})
@@ -118,7 +119,7 @@ def extra_configs(dev, B):
             p_.grad = None
         ml(x).backward(Gl)
     fl_lr = 3 * T * 2 * (F * r + r * HL + HL * r + r * HL)            # fwd 2 534 400 per utterance, x3 fwd+bwd
-    res["lowrank_r16_h256"] = entry(_time_steps(step_lr, 3, 10, 5), B * 342144, B * fl_lr,
+    res["lowrank_r16_h256"] = entry(_time_steps(step_lr, 5, 10, 20), B * 342144, B * fl_lr,
                                     "low-rank fwd+bwd, wRank=uRank=16 H=256 F=32 T=99 fp32 (BASELINE config 4)",
                                     {"forward": fastgrnn_cuda.kernel_path(T, B, F, HL, r, r, direction=0, flags=4),
                                      "backward": fastgrnn_cuda.kernel_path(T, B, F, HL, r, r, direction=1, flags=4)})
@@ -136,12 +137,36 @@ def extra_configs(dev, B):
             p_.grad = None
         ms.init_hidden()
         ms.loss(x, y).backward()
+    # the batched frame GEMM of the second layer, X[T*B,256] . W^T[256,128] -- the one place of the model where
+    # `north_star` wants the matrix pipe ("MFMA used only for the batched Wx_t frame GEMM"): timed by itself through its
+    # C-ABI entry, MFMA utilisation against the dense bf16 peak (every fp32 product is six bf16 MFMA terms)
+    hs1 = torch.randn(T * B, 256, generator=g).to(dev)
+    w2l = ms.rnn_list[1].W.detach()
+    for _ in range(5):
+        fastgrnn_cuda.frame_gemm(hs1, w2l)
+    torch.cuda.synchronize()
+    smp = []
+    fastgrnn_cuda._timing = smp
+    for _ in range(20):
+        fastgrnn_cuda.frame_gemm(hs1, w2l)
+    torch.cuda.synchronize()
+    fastgrnn_cuda._timing = None
+    ms_g = sorted(a.elapsed_time(b) for _, a, b in smp)[len(smp) // 2]
+    fl_g = 2.0 * T * B * 256 * 128
+    wx = {"kernel": "rows_gemm_split<8,8> (fastgrnn_hip_frame_gemm): P[T*B,128] = X[T*B,256] . W^T, layer 2 of the stack",
+          "avg_launch_ms": ms_g, "tflops_f32_equiv": fl_g / (ms_g * 1e-3) / 1e12,
+          "mfma": {"dtype": "bf16 x3 planes, 6 terms", "executed_tflops": 6 * fl_g / (ms_g * 1e-3) / 1e12,
+                   "peak": PEAK_BF16_TFLOPS, "frac": 6 * fl_g / (ms_g * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
+          "hbm": {"bytes": T * B * (256 + 128) * 4, "gbs": T * B * (256 + 128) * 4 / (ms_g * 1e-3) / 1e9,
+                  "frac": T * B * (256 + 128) * 4 / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    del hs1
     fl_stack = 3 * T * 2 * (F * 256 + 256 * 256 + 256 * 128 + 128 * 128)
-    res["stack_2layer"] = entry(_time_steps(step_stack, 3, 10, 5), B * (4 * T * F + 8), B * fl_stack,
+    res["stack_2layer"] = entry(_time_steps(step_stack, 5, 10, 20), B * (4 * T * F + 8), B * fl_stack,
                                 "RNNClassifierModel 32->256->128 dense + fused head, training step (trainingConfig.py:12-15, "
                                 "model.py:196-230); algorithmic bytes = read x + labels (d_x is not requested)",
                                 {"layer1": [fastgrnn_cuda.kernel_path(T, B, F, 256, direction=d_, flags=4) for d_ in (0, 1)],
                                  "layer2": [fastgrnn_cuda.kernel_path(T, B, 256, 128, direction=d_, flags=4 | (256 if d_ else 0)) for d_ in (0, 1)]})
+    res["stack_2layer"]["wx_gemm"] = wx
     return res
 
 
@@ -190,13 +215,22 @@ def main():
     params = [p for p in model.parameters()]
     bucket = GradBucket(params, world) if world > 1 else None
 
+    ar_events = []                                # (start, end) around the gradient all-reduce, every fourth step
+
     def step():
         for p in params:
             p.grad = None
         hs = model(x)
         hs.backward(G)                            # L = sum(hs*G): dL/dhs = G
         if bucket is not None:
-            bucket.all_reduce_()
+            if fastgrnn_cuda._timing is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bucket.all_reduce_()
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                bucket.all_reduce_()
 
     eager_step = step
     if args.graph:
@@ -272,10 +306,55 @@ def main():
         blocks.append((time.perf_counter() - tb) / args.steps)
     blocks.sort()
     ms_median_blocks = 1e3 * blocks[len(blocks) // 2]
+    # second headline leg (N = 1, default run): the SAME step captured once in a HIP graph (kws_amd.GraphedStep) and
+    # replayed -- the same kernels with ~10 us of host work per step instead of the eager path's 120-270, i.e. what the
+    # GPU side alone allows.  Same protocol: W warmup replays, K timed replays between synchronises, and the median
+    # of ten further K-step blocks.
+    graph_leg = None
+    if world == 1 and not args.graph:
+        try:
+            from kws_amd import GraphedStep
+            gstep = GraphedStep(eager_step)
+            # (the capture leaves the queue idle for a while: the same untimed spin-up as the eager leg, then W warmups)
+            for _ in range(int(args.spinup_ms / max(1e-3, ms_median_blocks)) + max(args.warmup, 5)):
+                gstep()
+            _st = torch.cuda.current_stream(dev)
+            while not _st.query():
+                pass
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                gstep()
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - tg
+            gblocks = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(args.steps):
+                    gstep()
+                torch.cuda.synchronize()
+                gblocks.append((time.perf_counter() - tb) / args.steps)
+            gblocks.sort()
+            graph_leg = {"host": "hip_graph_replay", "value": B * args.steps / dtg, "unit": "utterances/s",
+                         "ms_per_step": 1e3 * dtg / args.steps, "ms_per_step_median_of_blocks": 1e3 * gblocks[5],
+                         "steps": args.steps, "note": "kws_amd.GraphedStep: module forward + autograd backward captured once, "
+                                                      "replayed; results bit-equal to the eager step (tests/test_hip_graph.py)"}
+            del gstep
+        except Exception as e:                     # the eager line stands on its own
+            graph_leg = {"host": "hip_graph_replay", "error": repr(e)}
+    ar_us = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank duration of the gradient all-reduce (events on the compute stream around bucket.all_reduce_(),
+        # sampled steps of the timed region): gathered so that the first multi-GPU run explains itself
+        mine = sorted(a.elapsed_time(b) * 1e3 for a, b in ar_events)
+        med = mine[len(mine) // 2] if mine else float("nan")
+        allr = [None] * world
+        dist.all_gather_object(allr, med)
+        ar_us = allr
 
     if rank == 0:
         ms_f = [a.elapsed_time(b) for tag, a, b in timing if tag == "forward"]
@@ -306,6 +385,10 @@ def main():
                       if args.io == "bf16" else
                       "f32 (split-precision MFMA: exact 3xbf16 planes, fp16 two-plane forward state product; fp32 accumulate)" if split else "f32"),
             "data": "synthetic", "host": "hip_graph_replay" if args.graph else "eager",
+            "graph_replay": graph_leg,
+            "allreduce_us": ({"per_rank_median": ar_us, "bytes": 4 * sum(bucket.sizes),
+                              "note": "events around GradBucket.all_reduce_() on the compute stream (one flat fp32 bucket, "
+                                      "ReduceOp.AVG on RCCL)"} if ar_us is not None else None),
             "config": {"workload": "FastGRNN dense fwd+bwd training step (FastGRNNCUDA module + autograd), T=99 F=32 "
                                    "H=128 B=%d per GPU, fp32 results, dense grad_hs; %s" % (
                                        B, "split-precision MFMA kernels, one saved [T,B,H] tensor" if split

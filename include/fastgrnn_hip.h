@@ -239,6 +239,15 @@ int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void *h_last, 
                            void *d_h_last, void *d_fc_w, void *d_fc_b,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* frame_gemm -- the one genuinely dense, non-recurrent contraction of a layer, as a call of its own:
+ *   P[rows, H] = X[rows, F] . W^T,   W:[H,F]  (rows = T*B; the reference computes it per step, `mm` at .cu:356).
+ * forward_unroll runs exactly this launch in front of the scan for layers whose input is wider than 32 (the scan of a
+ * 32-feature layer has the product fused); it is exported so that its MFMA utilisation can be measured and reported by
+ * itself (bench.py: `wx_gemm`).  fp32 (dtype FASTGRNN_F32) or bf16 x with fp32 p (FASTGRNN_BF16_IO); (H, F) one of
+ * the wide-layer shapes of the table above, else FASTGRNN_ERR_UNSUPPORTED.  No workspace. */
+int fastgrnn_hip_frame_gemm(size_t rows, int32_t H, int32_t F, const void *x, const void *w, void *p, int32_t dtype,
+                            void *stream);
+
 /* Test hook, not part of the reference boundary: one launch that leaves `pattern` in every CU's LDS and vector
  * registers (on-chip state is not cleared between kernels).  tests/test_hip_state_independence.py runs it before the
  * operators with a NaN pattern: results must not change, i.e. no kernel reads LDS or registers it did not write. */

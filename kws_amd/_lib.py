@@ -36,6 +36,7 @@ EXPORTS = (
     "fastgrnn_hip_forward_unroll", "fastgrnn_hip_backward_unroll",
     "fastgrnn_hip_forward", "fastgrnn_hip_backward",
     "fastgrnn_hip_head_workspace_bytes", "fastgrnn_hip_head_xent", "fastgrnn_hip_debug_poison_cu_state",
+    "fastgrnn_hip_frame_gemm",
 )
 
 
@@ -102,6 +103,8 @@ def load():
     lib.fastgrnn_hip_head_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.fastgrnn_hip_head_xent.restype = i32
     lib.fastgrnn_hip_head_xent.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.fastgrnn_hip_frame_gemm.restype = i32
+    lib.fastgrnn_hip_frame_gemm.argtypes = [sz, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp]
     if lib.fastgrnn_hip_abi_version() != ABI_VERSION:
         raise FastGRNNLibraryError("ABI version mismatch: library %d, binding %d"
                                    % (lib.fastgrnn_hip_abi_version(), ABI_VERSION))

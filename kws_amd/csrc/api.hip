@@ -166,6 +166,16 @@ int fastgrnn_hip_head_xent(int32_t B, int32_t H, int32_t C, const void* h_last, 
                    reinterpret_cast<hipStream_t>(stream));
 }
 
+int fastgrnn_hip_frame_gemm(size_t rows, int32_t H, int32_t F, const void* x, const void* w, void* p, int32_t dtype,
+                            void* stream) {
+  if (!x || !w || !p) return FASTGRNN_ERR_NULL_POINTER;
+  if (rows < 1 || H < 1 || F < 1) return FASTGRNN_ERR_BAD_SHAPE;
+  if (dtype != FASTGRNN_F32 && dtype != FASTGRNN_BF16_IO) return FASTGRNN_ERR_BAD_DTYPE;
+  if (!rows_gemm_supported(H, F, false)) return FASTGRNN_ERR_UNSUPPORTED;
+  return rows_gemm(rows, H, F, false, x, reinterpret_cast<const float*>(w), p, dtype == FASTGRNN_BF16_IO, false,
+                   reinterpret_cast<hipStream_t>(stream));
+}
+
 int fastgrnn_hip_debug_poison_cu_state(uint32_t pattern, void* stream) {
   return debug_poison(pattern, reinterpret_cast<hipStream_t>(stream));
 }

@@ -60,6 +60,9 @@ class FastGRNNFunction(Function):
         return _as_autograd_grads(outputs, ctx.needs_input_grad)
 
 
+_unroll_decisions = {}
+
+
 class FastGRNNUnrollFunction(Function):
     """rnn.py:907-972.  Same inputs, same gradients; what is SAVED between the two passes is
     an internal matter: on the split-precision kernel path the forward keeps one auxiliary
@@ -75,30 +78,40 @@ class FastGRNNUnrollFunction(Function):
         (model.py:227) -- so that the backward receives a [B,H] gradient instead of the dense, all-but-one-
         step-zero [T,B,H] tensor autograd builds for ``hs[-1]`` (FLAG_GRAD_LAST: not written, not read)."""
         old_h = old_h.contiguous()
-        if batch_major:
-            B, T, F = input.shape
-        else:
-            T, B, F = input.shape
-        H = old_h.shape[1]
-        rw = w1.shape[0] if w1.numel() else 0
-        ru = u1.shape[0] if u1.numel() else 0
-        # The trainer hands over permute(2,0,1) of the loader's [B,F,T] batch (trainClassifier.py:204,299), a
-        # [T,B,F] VIEW; the reference copies it here with .contiguous().  Where the kernels can read [B,F,T]
-        # in place (FLAG_X_BFT) the view's base is passed instead and d_input comes back as the same view.
-        x_bft = (not batch_major and input.is_cuda and not input.is_contiguous()
-                 and input.permute(1, 2, 0).is_contiguous()
-                 and input.dtype in (torch.float32, torch.bfloat16)
-                 and fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
-                                               _lib.FLAG_SAVE_PREACT | _lib.FLAG_X_BFT) == 2)
+        # Which contract / layout flags this call runs under is a pure function of its shapes, dtype and strides:
+        # decided once per signature (three descriptor look-ups), then one dictionary hit per step.
+        key = (input.shape, input.stride(), input.dtype, input.is_cuda, old_h.shape, w1.shape, u1.shape,
+               gate_non_linearity, batch_major, last_state)
+        dec = _unroll_decisions.get(key)
+        if dec is None:
+            if batch_major:
+                B, T, F = input.shape
+            else:
+                T, B, F = input.shape
+            H = old_h.shape[1]
+            rw = w1.shape[0] if w1.numel() else 0
+            ru = u1.shape[0] if u1.numel() else 0
+            # The trainer hands over permute(2,0,1) of the loader's [B,F,T] batch (trainClassifier.py:204,299), a
+            # [T,B,F] VIEW; the reference copies it here with .contiguous().  Where the kernels can read [B,F,T]
+            # in place (FLAG_X_BFT) the view's base is passed instead and d_input comes back as the same view.
+            x_bft = (not batch_major and input.is_cuda and not input.is_contiguous()
+                     and input.permute(1, 2, 0).is_contiguous()
+                     and input.dtype in (torch.float32, torch.bfloat16)
+                     and fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
+                                                   _lib.FLAG_SAVE_PREACT | _lib.FLAG_X_BFT) == 2)
+            preact = (input.dtype in (torch.float32, torch.bfloat16) and input.is_cuda and
+                      fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
+                                                _lib.FLAG_SAVE_PREACT) == 2)
+            flags = _lib.FLAG_SAVE_PREACT if preact else 0
+            if batch_major:
+                flags |= _lib.FLAG_BATCH_MAJOR
+            if x_bft:
+                flags |= _lib.FLAG_X_BFT
+            grad_last = bool(last_state and input.is_cuda and fastgrnn_cuda.kernel_path(
+                T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1, flags | _lib.FLAG_GRAD_LAST) == 2)
+            dec = _unroll_decisions[key] = (x_bft, preact, flags, grad_last)
+        x_bft, preact, flags, grad_last = dec
         input = input.permute(1, 2, 0) if x_bft else input.contiguous()
-        preact = (input.dtype in (torch.float32, torch.bfloat16) and input.is_cuda and
-                  fastgrnn_cuda.kernel_path(T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1,
-                                            _lib.FLAG_SAVE_PREACT) == 2)
-        flags = _lib.FLAG_SAVE_PREACT if preact else 0
-        if batch_major:
-            flags |= _lib.FLAG_BATCH_MAJOR
-        if x_bft:
-            flags |= _lib.FLAG_X_BFT
         ctx.flags = flags
         outputs = fastgrnn_cuda.forward_unroll(input, w, u, bias_gate, bias_update, zeta, nu, old_h,
                                                gate_non_linearity, w1, w2, u1, u2, flags=flags)
@@ -115,8 +128,7 @@ class FastGRNNUnrollFunction(Function):
         ctx.preact = preact
         ctx.last_state = bool(last_state)
         if last_state:
-            ctx.grad_last = (input.is_cuda and fastgrnn_cuda.kernel_path(
-                T, B, F, H, rw, ru, gate_non_linearity, 2, input.dtype, 1, flags | _lib.FLAG_GRAD_LAST) == 2)
+            ctx.grad_last = grad_last
             return (hidden_states[:, -1] if batch_major else hidden_states[-1]).clone()
         return hidden_states
 

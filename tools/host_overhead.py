@@ -55,3 +55,20 @@ for _ in range(n):
     step()
 torch.cuda.synchronize()
 print("B=16: %.1f us/step (serial-chain / host floor)" % (1e6 * (time.perf_counter() - t0) / n))
+# the host's own cost: the same calls on a two-frame sequence (the GPU side is a few microseconds, so the loop time is
+# what the host spends per step: module forward + autograd + the ctypes shim + three launches).  A/B in ONE process
+# (the same loop differs by 2x between processes on one box): with and without the shim's validated-signature path.
+x, G = xs[:2].contiguous(), Gs[:2].contiguous()
+for _ in range(200):
+    step()
+torch.cuda.synchronize()
+for rep in range(6):
+    _fc._use_seen = (rep % 2 == 0)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print("T=2 B=16, %s: host %.1f us/step" % ("validated-signature path" if _fc._use_seen else "full checks every call",
+                                                1e6 * (t1 - t0) / n))
+_fc._use_seen = True
