@@ -117,6 +117,22 @@ CASES = [
 ]
 
 
+def _keep_relu_gates_off_the_kink(p, x, h0, margin=1e-4):
+    """Nudge bias_gate, unit by unit, until no relu-gate pre-activation a = pre + b_z of the whole sequence lies within
+    `margin` of zero (fp64 oracle; the recurrence moves with the bias, so a few rounds).  pre is recovered from the
+    update nonlinearity's output, c = tanh(pre + b_h)."""
+    p = {k: v.copy() for k, v in p.items()}
+    for _ in range(50):
+        p64 = {k: v.astype(np.float64) for k, v in p.items()}
+        _, _, cs = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate="relu")
+        a = np.arctanh(np.clip(cs, -1 + 1e-15, 1 - 1e-15)) - p64["bias_update"] + p64["bias_gate"]
+        close = np.abs(a).reshape(-1, a.shape[-1]).min(axis=0) < 2 * margin     # units with a value near the kink
+        if not close.any():
+            return p
+        p["bias_gate"][0, close] += np.float32(7 * margin)
+    raise AssertionError("could not move the relu gates off the kink")
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "T%dB%dF%dH%dr%d-%d%s" % c)
 @pytest.mark.parametrize("flags", [0, FORCE_F32_MFMA, FORCE_GENERIC], ids=["dispatch", "f32mfma", "generic"])
 def test_seeded_vs_oracle_fp32(case, flags):
@@ -132,6 +148,8 @@ def test_seeded_vs_oracle_fp32(case, flags):
     x = rng.standard_normal((T, B, F)).astype(np.float32)
     h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
     G = rng.standard_normal((T, B, H)).astype(np.float32)
+    if gate == "relu":
+        p = _keep_relu_gates_off_the_kink(p, x, h0)
     hs, zs, cs, g = run_hip(x, h0, G, p, gate, flags=flags)
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64), gate=gate)
@@ -140,14 +158,11 @@ def test_seeded_vs_oracle_fp32(case, flags):
     # 1e-5 absolute while |h| <= 1, relative beyond (a tanh/relu gate does not bound h)
     assert (np.abs(hs - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
     assert (np.abs(zs - zs_o) / np.maximum(1.0, np.abs(zs_o))).max() <= 1e-5 and np.abs(cs - cs_o).max() <= 1e-5
-    if gate == "relu":
-        # a relu gate is discontinuous in its derivative: fp32-vs-fp64 sign flips of
-        # pre-activations within 1e-6 of zero change d_pre by O(1); compare against the
-        # oracle run in fp32 on the HIP path's own z (same mask) instead.
-        g_o = O.unroll_backward(G, x, hs, zs, cs, p, h0, gate=gate)
-        _check_grads(g, {k: v for k, v in g_o.items()}, 5e-5, case)
-    else:
-        _check_grads(g, g_o, 2e-5, case)
+    # relu included: its derivative jumps at zero, but no gate pre-activation of these cases comes within 1e-4 of the
+    # kink (_keep_relu_gates_off_the_kink), 1e2 times what fp32 and fp64 can differ by there -- the masks agree, and the
+    # comparison is the fp64 one of every other gate.  (Round 2 compared the relu cases with the oracle run in fp32 on
+    # the kernel's OWN z: a same-mask self-consistency check.)
+    _check_grads(g, g_o, 2e-5, case)
 
 
 @pytest.mark.parametrize("lowrank", [False, True])
