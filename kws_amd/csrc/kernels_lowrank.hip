@@ -270,14 +270,6 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   __shared__ float red[2 * NW];
   __shared__ __attribute__((aligned(16))) unsigned char wimg[NW][3 * IMG_PLANE];   // wave-private: d_pre_t, h_{t-1}, d_m_t
   __shared__ __attribute__((aligned(16))) unsigned char simg[2][2][3 * IMG_PLANE]; // shared, by step parity: m_t [b][32 j], x_t [b][32 f]
-  // The factor fragments are PARKED in LDS in fragment order and read back each step for the phase that uses them
-  // ([U2|W2]^T in front of the barrier, U1^T and W1^T behind it): registers are what this kernel is short of (28
-  // accumulators + a step of operands in flight + the operands of the products that trail into the next step), LDS
-  // bandwidth is not.
-  __shared__ __attribute__((aligned(16))) u32x4 uw2tl[NW][2][3][64];
-  __shared__ __attribute__((aligned(16))) uint2 u1tl[NW][NT][3][64];
-  __shared__ __attribute__((aligned(16))) uint2 w1tl[2][3][64];
-
 #ifdef FASTGRNN_DIAG_STAMPS
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
@@ -295,8 +287,11 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   const float sn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fsigmoid(nu[0]))));
   if (tid < H) { sbias[0][tid] = bz[tid]; sbias[1][tid] = bh[tid]; }
 
-  // ---- A operands ---------------------------------------------------------------------------
+  // ---- resident A operands -------------------------------------------------------------------
+  // (Round 3's first in-scan build parked all three in LDS and re-read them every step: with the operand set refilled
+  // by buffer loads and the rank-space products on the K = 16 MFMA form they fit beside everything else again.)
   // d_m[j][b] = sum_n [U2|W2][n][j] d_pre[b][n] over own units (K = 32): tile 0 rows = U2 columns, tile 1 = W2 columns
+  Frag3 UW2Tf[2];
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     const float* src = tl == 0 ? u2 : w2;
@@ -308,18 +303,11 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
       lo[j] = i < rk ? src[(size_t)(n0 + j) * rk + ic] : 0.f;
       hi[j] = i < rk ? src[(size_t)(n0 + 4 + j) * rk + ic] : 0.f;
     }
-    const Frag3 f = split3(lo, hi);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) uw2tl[wv][tl][pl][l] = f.p[pl];
+    UW2Tf[tl] = split3(lo, hi);
   }
-  auto load_uw2t = [&](Frag3 (&f)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) f[tl].p[pl] = uw2tl[wv][tl][pl][l];
-  };
   // d_h[k][b] = z*g + sum_j U1[j][k] d_m_h[j][b]: rows = own units (row 4c + r of tile mt = unit 8c + 4mt + r of the
   // wave, the unit lane (b, c) holds as element r of tile mt), K = the 16 rank rows: lane group g holds j = 4g..4g+3
+  Half3 U1Tf[NT], W1Tf;
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {
     const int kA = wv * UPW + (i >> 2) * UPL + mt * 4 + (i & 3);
@@ -328,28 +316,18 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     for (int j = 0; j < 4; ++j) v[j] = 4 * g + j < ru ? u1[(size_t)(4 * g + j) * H + kA] : 0.f;
     uint2 q0, q1, q2;
     split_quad(v, q0, q1, q2);
-    u1tl[wv][mt][0][l] = q0; u1tl[wv][mt][1][l] = q1; u1tl[wv][mt][2][l] = q2;
+    U1Tf[mt].p[0] = __builtin_bit_cast(s16x4, q0); U1Tf[mt].p[1] = __builtin_bit_cast(s16x4, q1); U1Tf[mt].p[2] = __builtin_bit_cast(s16x4, q2);
   }
-  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv (waves 0, 1), K = the 16 rank rows
-  if (wv < 2) {
-    const int f = wv * 16 + i;
+  // d_x[f][b] = sum_j W1[j][f] d_m_x[j][b]: feature tile wv & 1 (used by waves 0, 1), K = the 16 rank rows
+  {
+    const int f = (wv & 1) * 16 + i;
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = 4 * g + j < rw ? w1[(size_t)(4 * g + j) * F + f] : 0.f;
     uint2 q0, q1, q2;
     split_quad(v, q0, q1, q2);
-    w1tl[wv][0][l] = q0; w1tl[wv][1][l] = q1; w1tl[wv][2][l] = q2;
+    W1Tf.p[0] = __builtin_bit_cast(s16x4, q0); W1Tf.p[1] = __builtin_bit_cast(s16x4, q1); W1Tf.p[2] = __builtin_bit_cast(s16x4, q2);
   }
-  auto load_u1t = [&](Half3 (&f)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) f[mt].p[pl] = __builtin_bit_cast(s16x4, u1tl[wv][mt][pl][l]);
-  };
-  auto load_w1t = [&](Half3& f) __attribute__((always_inline)) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) f.p[pl] = __builtin_bit_cast(s16x4, w1tl[wv & 1][pl][l]);
-  };
 
   f32x4 sbz[NT], sbh[NT], dh[NT];
 #pragma unroll
@@ -561,8 +539,6 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
       *reinterpret_cast<unsigned short*>(so + 4 * IMG_PLANE) = s1;
       *reinterpret_cast<unsigned short*>(so + 5 * IMG_PLANE) = s2;
     }
-    Frag3 UW2Tf[2];
-    load_uw2t(UW2Tf);
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(1)
     load_ew_mx(tn, e);
@@ -585,9 +561,6 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
     const unsigned trs_cur = trs_off + cur * (6 * IMG_PLANE);
     tr_half_at(trs_cur, Bm[0]); tr_half_at(trs_cur + 32, Bm[1]);
     if (xwave) tr_half_at(trs_cur + 3 * IMG_PLANE + (wv & 1) * 32, Ax);
-    Half3 U1Tf[NT], W1Tf;
-    load_u1t(U1Tf);
-    if (wv < 2) load_w1t(W1Tf);
     f32x4 dmh = f32x4{0.f, 0.f, 0.f, 0.f}, dmx = dmh;
 #pragma unroll
     for (int w2i = 0; w2i < NW; ++w2i) dmh += *reinterpret_cast<const f32x4*>(&mp[cur][w2i][i][4 * g]);
@@ -645,7 +618,7 @@ __global__ __launch_bounds__(512) void bwd_scan_lowrank_split(
   };
 
   EwOps ea;                                          // ONE operand set, refilled right behind its use (see step)
-  __syncthreads();                                   // sbias, parked fragments
+  __syncthreads();                                   // sbias
   load_ew(Tn - 1, ea);
   for (int t = Tn - 1; t >= 0; --t) step(t, ea);
   trailing_products_a(); trailing_products_b();      // step 0's
