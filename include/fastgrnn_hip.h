@@ -166,11 +166,16 @@ const char *fastgrnn_hip_status_string(int status);
  *                                 calls, 25 us at B = 4096; d_x comes back as [B,F,T]); last-state
  *                                 flags; gates sigmoid / relu / tanh with the reference's (z_s, h_prime_s)
  *                                 tensors, every gate under FASTGRNN_FLAG_SAVE_PREACT.
+ *   dense  H=256, F=64/128        (F = 64: the reference's DEFAULT first layer, feature_type='delta' = 32 MFCCs + 32
+ *                                 deltas, trainingConfig.py:36, mfccProcessor.py:27-28) fp32, time-major; as F=32
+ *                                 but without FASTGRNN_FLAG_X_BFT: the frame product X.W^T is one batched GEMM into
+ *                                 the workspace (T*B*256*4 bytes more of it) in front of the scan.
  *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are
  *                                 zero-extended to 16 inside the kernels): gates sigmoid / relu / tanh; all layout
  *                                 flags; backward under FASTGRNN_FLAG_SAVE_PREACT only.
- *   every other factorised cell on one of the dense shapes above (H=128 with any ranks; H=256, F=32 with a rank of
- *                                 17..256 or with only one of W, U factorised: rnn.py:783-798): the factors are
+ *   every other factorised cell on one of the dense shapes above (H=128 with any ranks; H=256: F=32 with a rank of
+ *                                 17..256 or with only one of W, U factorised, F=64/128 with any ranks:
+ *                                 rnn.py:783-798): the factors are
  *                                 multiplied out per call, the dense kernels run, the dense gradients are
  *                                 projected onto the factors (as the reference's CUDA operator does for every
  *                                 low-rank cell, .cu:353-362,546-555); the dense shape's limits and flags apply.

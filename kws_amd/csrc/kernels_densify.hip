@@ -67,7 +67,8 @@ void densify(const fastgrnn_desc& d, const fastgrnn_params& p, char* base, const
 
 bool densified_shape(const fastgrnn_desc& d) {
   return (d.w_rank > 0 || d.u_rank > 0) && d.w_rank <= d.H && d.u_rank <= d.H && !lowrank_shape(d) &&
-         ((d.H == 256 && d.F == 32) || (d.H == 128 && (d.F == 32 || d.F == 64 || d.F == 128 || d.F == 256)));
+         ((d.H == 256 && (d.F == 32 || d.F == 64 || d.F == 128)) ||
+          (d.H == 128 && (d.F == 32 || d.F == 64 || d.F == 128 || d.F == 256)));
 }
 
 bool densified_supported(const fastgrnn_desc& d, int direction) {

@@ -39,7 +39,11 @@ constexpr int SLAB2 = 576;                      // floats per workgroup: d_bz[25
 // set their word of `flags` and leave at once.  MODE 2: bf16 path for exactly those workgroups (launched right behind
 // MODE 1 on the same stream; a workgroup whose flag is clear leaves at once).  Two kernels instead of one with both
 // paths inside: together they needed a dozen registers more than a wave has, i.e. spill reloads inside the loop.
-template <int GATE, int AUX, bool RAGGED, int MODE>
+// PREIN: the layer's input is wider than 32 (F = 64: the reference's default feature type, mfcc + delta,
+// trainingConfig.py:36, mfccProcessor.py:27-28; F = 128) -- W no longer fits beside U, and its product with the frames
+// has no recurrence in it: `x` is then P[T*B, 256] = X . W^T, written by the batched frame GEMM (kernels_gemm.hip) in
+// front of this launch, and the scan reads P(t) where it otherwise runs its W.x MFMAs (as the H = 128 wide layers do).
+template <int GATE, int AUX, bool RAGGED, int MODE, bool PREIN = false>
 __global__ __launch_bounds__(512) void fwd_scan_h256(
     int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
@@ -147,11 +151,13 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
           u2l[((wv * 2 + mt) * KS2 + s) * 64 + l] = f.p[2];
         }
       }
-      const float* wp = w + (size_t)nA * F2 + 8 * g;
-      Wf[mt] = split3(ld4(wp), ld4(wp + 4));
-      if (H16) {
+      if (!PREIN) {
+        const float* wp = w + (size_t)nA * F2 + 8 * g;
+        Wf[mt] = split3(ld4(wp), ld4(wp + 4));
+        if (H16) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wfl[((wv * 2 + mt) * 3 + p) * 64 + l] = Wf[mt].p[p];
+          for (int p = 0; p < 3; ++p) wfl[((wv * 2 + mt) * 3 + p) * 64 + l] = Wf[mt].p[p];
+        }
       }
     }
   }
@@ -184,6 +190,12 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
   };
   const float* xlane = x + (size_t)xbc * F2 + xf;          // this lane's value of frame t: xlane[t * B * F]
   auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * B * F2]; };
+  // PREIN: this lane's eight values of P(t) (rows of lanes beyond a ragged batch: the last utterance's)
+  const float* plane = x + (size_t)bc * H2 + n0;
+  auto load_p = [&](int t, f32x4 (&q)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) q[mt] = ld4(plane + (size_t)t * B * H2 + 16 * mt);
+  };
   const unsigned lane_hs = (unsigned)b * H2 + n0;
   auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
@@ -201,15 +213,23 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
 
   __syncthreads();                                   // sbias staged; bf16 path: every wave's plane-2 fragments written
   publish_h(0);
-  publish_x(0, load_x(0));
-  float xnext = load_x(Tn > 1 ? 1 : 0);              // frame t+1, published during step t
+  float xnext = 0.f;
+  f32x4 pnext[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (PREIN) {
+    load_p(0, pnext);
+  } else {
+    publish_x(0, load_x(0));
+    xnext = load_x(Tn > 1 ? 1 : 0);                  // frame t+1, published during step t
+  }
   __syncthreads();
 
   f32x4 aux_prev[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   for (int t = 0; t < Tn; ++t) {
     const int cur = H16 ? (t & 1) : 0, nxt = H16 ? (cur ^ 1) : 0;
     const float xpub = xnext;
-    xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
+    const f32x4 pcur[2] = {pnext[0], pnext[1]};
+    if (PREIN) load_p(t + 1 < Tn ? t + 1 : Tn - 1, pnext);
+    else xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
     const unsigned char* hp = hpl + cur * NPL * PLH2;
     const unsigned char* xp = xpl + cur * 3 * PLX2;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -218,7 +238,10 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     constexpr int KB = H16 ? 4 : 2;                  // K-steps per fragment batch
     // every fragment read of a batch is ISSUED, each into registers of its own, before the first MFMA that reads
     // one; a batch's registers are reloaded only after its MFMAs have retired (operand rule)
-    {
+    if constexpr (PREIN) {
+      if (t > 0) store_step(t - 1, aux_prev);
+      a[0] = pcur[0]; a[1] = pcur[1];                // W.x_t, from the frame GEMM (.cu:356 for all steps at once)
+    } else {
       // ---- batch W: the frame product W.x_t (.cu:356) ---------------------------------------------------------
       Frag3 xB, Wl[2];
 #pragma unroll
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     }
     if (!H16) {                                      // single-buffered planes: everyone has read h_{t-1}, x_t by now
       lds_barrier();
-      publish_x(0, xpub);
+      if (!PREIN) publish_x(0, xpub);
     }
     publish_h(nxt);
     lds_barrier();
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     float probe = hown[0][0];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      if (!H16) keep_alive(probe, Wf[mt]);
+      if (!H16 && !PREIN) keep_alive(probe, Wf[mt]);
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         if (H16) asm volatile("" : "+v"(probe) : "v"(Uh[mt][s].hi), "v"(Uh[mt][s].lo));
@@ -667,7 +690,7 @@ H256BwdWs h256_bwd_layout(const fastgrnn_desc& d) {
   H256BwdWs L; size_t o = 0;
   L.part = o; o += align256(nwg * SLAB2 * 4);
   L.dpre = o; o += align256((TB + 16) * H2 * 4);     // + 16 sink rows for the lanes beyond a ragged batch
-  const size_t tn_u = tn_gemm_big_ws(TB, H2, H2), tn_w = tn_gemm_big_ws(TB, H2, F2);
+  const size_t tn_u = tn_gemm_big_ws(TB, H2, H2), tn_w = tn_gemm_big_ws(TB, H2, d.F);
   L.tn = o; o += tn_u > tn_w ? tn_u : tn_w;
   // FASTGRNN_FLAG_X_BFT: the time-major copy of x for the dW GEMM; the d_x GEMM then writes over it and the result is
   // transposed into the caller's [B,F,T] tensor
@@ -690,6 +713,13 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
     bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
     x = xtm;
   }
+  // a wider input (F = 64 / 128): the batched frame GEMM  P = X . W^T  into the workspace, then the PREIN scan on P
+  const bool prein = d.F != F2;
+  if (prein) {
+    float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + h256_flag_bytes(d));
+    rows_gemm((size_t)d.T * d.B, H2, d.F, false, x, (const float*)p.w, P, false, false, s);
+    x = P;
+  }
   auto go = [&](auto kern) __attribute__((always_inline)) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
@@ -700,14 +730,18 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
   const bool h16 = BOUNDED && !(d.flags & FASTGRNN_FLAG_FWD_BF16X3);
   auto pick = [&](auto aux_tag) __attribute__((always_inline)) {
     constexpr int A = decltype(aux_tag)::value;
-    if constexpr (BOUNDED) {
-      if (h16) {                                     // fp16 launch, then the bf16 one for workgroups it turned down
-        if (ragged) { go(fwd_scan_h256<GATE, A, true, 1>); go(fwd_scan_h256<GATE, A, true, 2>); }
-        else        { go(fwd_scan_h256<GATE, A, false, 1>); go(fwd_scan_h256<GATE, A, false, 2>); }
-        return;
+    auto with = [&](auto prein_tag) __attribute__((always_inline)) {
+      constexpr bool PI = decltype(prein_tag)::value;
+      if constexpr (BOUNDED) {
+        if (h16) {                                   // fp16 launch, then the bf16 one for workgroups it turned down
+          if (ragged) { go(fwd_scan_h256<GATE, A, true, 1, PI>); go(fwd_scan_h256<GATE, A, true, 2, PI>); }
+          else        { go(fwd_scan_h256<GATE, A, false, 1, PI>); go(fwd_scan_h256<GATE, A, false, 2, PI>); }
+          return;
+        }
       }
-    }
-    if (ragged) go(fwd_scan_h256<GATE, A, true, 0>); else go(fwd_scan_h256<GATE, A, false, 0>);
+      if (ragged) go(fwd_scan_h256<GATE, A, true, 0, PI>); else go(fwd_scan_h256<GATE, A, false, 0, PI>);
+    };
+    if (prein) with(std::true_type{}); else with(std::false_type{});
   };
   if (aux == 3) pick(std::integral_constant<int, 3>{});
   else if (aux == 2) pick(std::integral_constant<int, 2>{});
@@ -740,11 +774,11 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
   float* xtm = (float*)(base + L.xtm);
   if (bft) bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
   const float* xr = bft ? xtm : (const float*)x;
-  tn_gemm_big_run(TB, H2, F2, dpre, H2, xr, xr, (size_t)0, F2, tn, (float*)g.d_w, F2, s);
+  tn_gemm_big_run(TB, H2, d.F, dpre, H2, xr, xr, (size_t)0, d.F, tn, (float*)g.d_w, d.F, s);
   // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N]); skipped when the caller does not want the input's gradient
   // (g.d_x == NULL: the first layer of a model, whose input is data)
   if (g.d_x) {
-    rows_gemm(TB, F2, H2, true, dpre, (const float*)p.w, bft ? (void*)xtm : g.d_x, false, false, s);
+    rows_gemm(TB, d.F, H2, true, dpre, (const float*)p.w, bft ? (void*)xtm : g.d_x, false, false, s);
     if (bft) bft_transpose_f32(d.B, d.T, xtm, (float*)g.d_x, false, s);
   }
 }
@@ -753,13 +787,14 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
 
 bool h256_shape(const fastgrnn_desc& d) {
   // B < 2^21: a step's rows are addressed with 32-bit lane offsets (B*H*4 bytes < 2^31)
-  return d.w_rank == 0 && d.u_rank == 0 && d.H == H2 && d.F == F2 && d.B < (1 << 21);
+  return d.w_rank == 0 && d.u_rank == 0 && d.H == H2 && (d.F == F2 || d.F == 64 || d.F == 128) && d.B < (1 << 21);
 }
 
 // time-major fp32 sequences, every gate, both saved-tensor contracts, full or last-state outputs / gradients
 bool h256_supported(const fastgrnn_desc& d, int direction) {
   if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
   if (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) return false;
+  if (d.F != F2 && (d.flags & FASTGRNN_FLAG_X_BFT)) return false;      // (the loader's [B,F,T] batches: 32 features)
   // 32-bit byte offsets inside the d_pre workspace, its 16 sink rows included
   if (((double)d.T * d.B + 16.0) * H2 * 4.0 >= 4294967296.0) return false;
   if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
@@ -770,8 +805,10 @@ bool h256_supported(const fastgrnn_desc& d, int direction) {
 size_t h256_backward_ws(const fastgrnn_desc& d) { return h256_bwd_layout(d).total; }
 // one word per workgroup: "my rows of h0 are outside the fp16 path's range" (fwd_scan_h256 MODE 1 -> MODE 2)
 // + under FASTGRNN_FLAG_X_BFT the time-major copy of x
+// + for F = 64 / 128 the frame product P[T*B, 256]
 size_t h256_forward_ws(const fastgrnn_desc& d) {
-  return h256_flag_bytes(d) + ((d.flags & FASTGRNN_FLAG_X_BFT) ? align256((size_t)d.T * d.B * F2 * 4) : 0);
+  return h256_flag_bytes(d) + ((d.flags & FASTGRNN_FLAG_X_BFT) ? align256((size_t)d.T * d.B * F2 * 4) : 0) +
+         (d.F != F2 ? align256((size_t)d.T * d.B * H2 * 4) : 0);
 }
 
 int h256_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x, const void* h0, void* hs, void* zs,

@@ -153,6 +153,9 @@ def main():
     run_case("g11_stack_l2_f32", 99, 4, 256, 128, "f32", 14, randomize_scalars=True)
     # G12: the whole default model -- both layers chained, last-state Linear, log_softmax, NLLLoss
     run_stack_case("g12_stack2_f64", 99, 4, 32, (256, 128), 12, "f64", 15)
+    # G13: the first layer of the model the reference ships and trains by default -- feature_type='delta'
+    # (trainingConfig.py:36) = 32 MFCCs + 32 deltas = 64 features (mfccProcessor.py:6,27-28) into 256 hidden units
+    run_case("g13_delta64_l1_f32", 99, 4, 64, 256, "f32", 16, randomize_scalars=True)
 
 
 if __name__ == "__main__":
