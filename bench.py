@@ -170,6 +170,38 @@ def extra_configs(dev, B):
     return res
 
 
+def make_step(model, x, G, params, bucket, ar_events=None, sample_allreduce=lambda: False):
+    """The benchmark's step: zero the gradients, module forward over [T,B,F], backward with the dense grad_hs, and -- data
+    parallel -- ONE all-reduce of the flat gradient bucket (kws_amd.dp.GradBucket).  `ar_events` collects (start, end)
+    events around the collective on the steps for which `sample_allreduce()` says so.  (A function of its own so that
+    tests/test_dp_gloo.py can run exactly this on CPU over gloo.)"""
+    def step():
+        for p in params:
+            p.grad = None
+        hs = model(x)
+        hs.backward(G)                            # L = sum(hs*G): dL/dhs = G
+        if bucket is not None:
+            if ar_events is not None and sample_allreduce():
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                bucket.all_reduce_()
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                bucket.all_reduce_()
+    return step
+
+
+def agree_on_count(n, world, device):
+    """Every step holds a collective: all ranks must run the SAME number of untimed spin-up steps (each sizes its own from
+    its own clock) -- the maximum over the ranks."""
+    if world <= 1:
+        return int(n)
+    ns = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+    return int(ns.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,21 +248,7 @@ def main():
     bucket = GradBucket(params, world) if world > 1 else None
 
     ar_events = []                                # (start, end) around the gradient all-reduce, every fourth step
-
-    def step():
-        for p in params:
-            p.grad = None
-        hs = model(x)
-        hs.backward(G)                            # L = sum(hs*G): dL/dhs = G
-        if bucket is not None:
-            if fastgrnn_cuda._timing is not None:
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                bucket.all_reduce_()
-                e1.record()
-                ar_events.append((e0, e1))
-            else:
-                bucket.all_reduce_()
+    step = make_step(model, x, G, params, bucket, ar_events, lambda: fastgrnn_cuda._timing is not None)
 
     eager_step = step
     if args.graph:
@@ -252,11 +270,7 @@ def main():
             step()
         torch.cuda.synchronize()
         est_ms = max(1e-3, (time.perf_counter() - t_spin) * 1e3 / 10)
-        n_spin = int(args.spinup_ms / est_ms)
-        if world > 1:                                      # every step holds a collective: all ranks run the SAME count
-            ns = torch.tensor([n_spin], dtype=torch.int64, device=dev)
-            dist.all_reduce(ns, op=dist.ReduceOp.MAX)
-            n_spin = int(ns.item())
+        n_spin = agree_on_count(int(args.spinup_ms / est_ms), world, dev)   # (every step holds a collective)
         for _ in range(n_spin):                            # enqueued back to back: continuous load, no host gaps
             step()
     for _ in range(args.warmup):

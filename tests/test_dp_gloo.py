@@ -203,3 +203,60 @@ def test_grad_bucket_detects_gradients_that_share_one_buffer():
     assert bucket.shared_flat_() is None
     params[1].grad = None
     assert bucket.shared_flat_() is None
+
+
+def _worker_bench_step(rank, world, port, q):
+    """bench.py's OWN step (bench.make_step) and spin-up agreement (bench.agree_on_count) over gloo, the CPU port as the
+    compute: after the step every rank holds, bit for bit, what one process gets by running the shards one after the
+    other and averaging -- SUM of two addends does not depend on their order, the scale by 1/2 is exact."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from kws_amd.dp import GradBucket, shard_batch
+        torch.set_num_threads(1)
+        T, B, F, H = 9, 22, 5, 12
+        torch.manual_seed(0)
+        model = _PortModule(F, H)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(T, B, F, generator=g)
+        G = torch.randn(T, B, H, generator=g)
+        params = list(model.parameters())
+        # every rank sizes its own spin-up; all must run the same number of (collective-holding) steps
+        n = bench.agree_on_count(3 + 2 * rank, world, torch.device("cpu"))
+        bucket = GradBucket(params, world)                     # mean over ranks (gloo: SUM + one scale)
+        step = bench.make_step(model, shard_batch(x, rank, world), shard_batch(G, rank, world), params, bucket)
+        for _ in range(n):
+            step()
+        got = [p.grad.clone() for p in params]
+        # one process, the shards one after the other
+        per_shard = []
+        for r in range(world):
+            for p in params:
+                p.grad = None
+            model(shard_batch(x, r, world)).backward(shard_batch(G, r, world))
+            per_shard.append([p.grad.clone() for p in params])
+        ok = n == 3 + 2 * (world - 1)
+        for k, a in enumerate(got):
+            ref = (per_shard[0][k] + per_shard[1][k]) * (1.0 / world)
+            ok = ok and torch.equal(a, ref)
+        q.put((rank, bool(ok), n))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_over_gloo_equals_the_single_process_average_bit_for_bit():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert {n for _, _, n in res} == {5}

@@ -30,6 +30,24 @@ ALL_SOURCES = [s for s, _ in SOURCES] + ["kernels_generic.hip", "kernels_head.hi
                                           "kernels_debug.hip"]
 
 
+@pytest.fixture(scope="session")
+def kernel_asm(tmp_path_factory):
+    """gfx950 assembly of every kernel source, compiled ONCE per session and four at a time (hipcc cross-compiles; the
+    two scanners then read the same files): name -> path."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = tmp_path_factory.mktemp("asm")
+
+    def one(name):
+        src = os.path.join(ROOT, "kws_amd", "csrc", name)
+        asm = out / (name + ".s")
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                        "-o", str(asm), src], check=True, capture_output=True, timeout=1500)
+        return name, str(asm)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return dict(ex.map(one, ALL_SOURCES))
+
+
 def _hipcc_version():
     try:
         out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout
@@ -40,13 +58,8 @@ def _hipcc_version():
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 @pytest.mark.parametrize("name,min_kernels", SOURCES, ids=[s[0] for s in SOURCES])
-def test_no_load_lands_behind_an_mfma_that_reads_its_target(tmp_path, name, min_kernels):
-    src = os.path.join(ROOT, "kws_amd", "csrc", name)
-    if not os.path.exists(src):
-        pytest.skip(name + " not present")
-    asm = tmp_path / (name + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                    "-o", str(asm), src], check=True, capture_output=True, timeout=1500)
+def test_no_load_lands_behind_an_mfma_that_reads_its_target(kernel_asm, name, min_kernels):
+    asm = kernel_asm[name]
     r = subprocess.run([sys.executable, SCAN, str(asm)], capture_output=True, text=True, timeout=900)
     lines = r.stdout.strip().splitlines()
     ver = _hipcc_version()
@@ -64,7 +77,7 @@ def test_no_load_lands_behind_an_mfma_that_reads_its_target(tmp_path, name, min_
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 @pytest.mark.parametrize("name", ALL_SOURCES)
-def test_no_lds_write_pending_at_a_branch_with_memory_instructions_behind_it(tmp_path, name):
+def test_no_lds_write_pending_at_a_branch_with_memory_instructions_behind_it(kernel_asm, name):
     """Second rule, by construction since round 3 and in EVERY kernel of the library: inside a loop no LDS
     write may be pending -- no `s_waitcnt lgkmcnt(0)` or barrier behind it on some path -- when a conditional branch,
     exec-masked or wave-uniform, with a vector-memory instruction within 12 instructions behind it is reached.  Round 2
@@ -73,10 +86,7 @@ def test_no_lds_write_pending_at_a_branch_with_memory_instructions_behind_it(tmp
     masked stores of the forward kernels, the F = 32 backward and the fallback scans were left alone.  The scanner
     walks the control-flow graph (loops = its strongly connected components).  The compiler this holds for is in the
     assertion message."""
-    src = os.path.join(ROOT, "kws_amd", "csrc", name)
-    asm = tmp_path / (name + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                    "-o", str(asm), src], check=True, capture_output=True, timeout=1500)
+    asm = kernel_asm[name]
     ver = _hipcc_version()
     for mode in ("--strict", "--narrow"):
         r2 = subprocess.run([sys.executable, LDS_SCAN, str(asm), mode], capture_output=True, text=True, timeout=900)
