@@ -201,9 +201,19 @@ void launch_rows_gemm(size_t R, const void* A, const float* W, void* C, bool bf_
 // workspace; tn_big_reduce sums them in a fixed order (deterministic, no atomics).
 // Rows of B below shiftB come from B0 (h0: H_prev of step 0), the rest from B1 shifted down by shiftB rows.
 constexpr int TNB_STAGE = 32;
+// Workgroup -> (row chunk, 128-column block of A).  The column blocks of ONE row chunk read the same rows of B: they
+// are given to workgroups 8 apart, which the dispatcher places on the same XCD (workgroups go round-robin over the 8
+// XCDs) in the same round, so the second read of those rows is a hit in that XCD's L2 and never reaches the fabric.
+// (Round 2 had them on neighbouring workgroups = neighbouring XCDs: the second read came from the Infinity Cache,
+// and the kernel sat at the ~5 TB/s the fabric delivers -- 1.25 GB per launch for 0.83 GB of operands.)
+__device__ __forceinline__ int tnb_chunk(int bid, int nblk) { return ((bid >> 3) / nblk) * 8 + (bid & 7); }
+__device__ __forceinline__ int tnb_mblk(int bid, int nblk) { return (bid >> 3) % nblk; }
+#ifndef TNW4_PRE
+#define TNW4_PRE 0                                // tn_gemm_w4: value pairs split before a stage's first MFMA (A/B knob)
+#endif
 
 template <int NT>
-__global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, int nchunk, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B0, const float* __restrict__ B1,
                                                    size_t shiftB, int ldb, float* __restrict__ part) {
   // wave tiling of the 8 x NT output tiles: MA m-tiles x NH n-tiles per wave.  4 x NT/4 where NT allows it (per stage
@@ -225,10 +235,8 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
 #endif
-  // consecutive workgroups take the column blocks of ONE row chunk: they run at the same time and read the same rows
-  // of B, so the second read comes from the Infinity Cache instead of HBM
-  const int mblk = blockIdx.x % nblk;              // 128-column block of A
-  const int chunk = blockIdx.x / nblk;
+  const int mblk = tnb_mblk(blockIdx.x, nblk), chunk = tnb_chunk(blockIdx.x, nblk);
+  if (chunk >= nchunk) return;                     // (grid padded to whole rounds of the XCDs; no barrier passed yet)
   const size_t nstages = (R + TNB_STAGE - 1) / TNB_STAGE;
   const size_t s_begin = (size_t)chunk * stages_per_wg;
   const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
@@ -358,6 +366,209 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
         pc[(size_t)((mq * MA + a) * 16 + 4 * g + r) * N + (nh * NH + c) * 16 + (l & 15)] = acc[a][c][r];
 }
 
+// ------------------------------------------------------------------------------------------
+// tn_gemm_w4 (N = 256): ONE wave per SIMD (workgroup = 4 waves), each 64 x 128 of the block (128 accumulator
+// registers in the AGPR half of the 512 a lone wave has), 192 MFMAs per stage with the split of its quarter of the NEXT
+// stage between them.  Why this shape (same-run A/B and cycle stamps, tools/gemm_ab_bench.hip):
+//   * tn_gemm_big's stage is 6 200 ticks for 3 072 MFMA cycles per SIMD: its two waves per SIMD do requests, fragment
+//     reads, products, split and publication one after the other and in lockstep.
+//   * Splitting the waves by ROLE (one MFMA wave + one load/split wave per SIMD; built, bit-identical, removed) is no
+//     faster: beside a wave that always has an MFMA ready the partner's vector instructions are issued at ~1 per 20
+//     ticks -- 5 100 ticks for the 252 of a stage's split, 67 of them waiting for data.  The MFMA wave alone runs a
+//     stage in 4 100 ticks (3 400 for the MFMAs = 17.7 each, 490 for the first fragment reads, 210 at the barrier).
+//   * Vector work between the MFMAs of the SAME wave is not free either (tools/mfma_shadow_probe.hip: +2.9 ticks per
+//     fp32 add / mul / fma behind a bf16 MFMA, ~0 for ONE integer or convert instruction, +3-4 for the second), but it
+//     costs about half of what it costs in a partner wave: 4 550 ticks for 192 MFMAs + 298 vector instructions.
+//   * v_dot2c_f32_bf16 for the residuals (7 instead of 11 instructions per value pair) is slower still (5 800): it
+//     competes with the MFMAs for the matrix pipe.  Splitting part of the next stage while the stage's first fragment
+//     reads are under way (PRE > 0) moves time from one segment to the other, no more.
+// Each 16-byte piece is re-requested for the stage after next (buffer load: descriptor in scalar registers, ONE
+// loop-invariant lane offset per operand, rows beyond R cut off by the descriptor's size -- no vector instruction) as
+// soon as it has been split: one stage of rows (48 KB per CU) is in flight at all times, every request has a whole
+// stage period to land, and the staging registers are 48.  Same sums in the same order as tn_gemm_big: bit-identical.
+// Requires shiftB to be 0, >= R or a multiple of the stage (no stage takes rows from both B0 and B1): the launcher
+// gives other shapes to tn_gemm_big.
+template <int NT, int PRE>
+__global__ __launch_bounds__(256) ONE_WAVE_PER_SIMD void tn_gemm_w4(size_t R, int stages_per_wg, int nblk, int nchunk, const float* __restrict__ A, int lda,
+                                                  const float* __restrict__ B0, const float* __restrict__ B1,
+                                                  size_t shiftB, int ldb, float* __restrict__ part) {
+  constexpr int MB = 128, N = 16 * NT, NH = NT / 2, NP = 256;
+  constexpr int ROWA = MB * 2 + 32, ROWB = N * 2 + 32;
+  constexpr int VA = TNB_STAGE * MB / 4 / NP, VB = TNB_STAGE * N / 4 / NP, VQ = VA + VB;   // 16-byte pieces per lane and stage
+  constexpr int PAIRS = 2 * VQ, PPT = (PAIRS - PRE) / NH;          // value pairs per lane and stage, per B tile
+  static_assert(NT % 2 == 0 && NH >= 3 && (PAIRS - PRE) % NH == 0 && PRE % 2 == 0 && (TNB_STAGE * N / 4) % NP == 0 && (TNB_STAGE * MB / 4) % NP == 0, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned char la[2][3][TNB_STAGE * ROWA];
+  __shared__ __attribute__((aligned(16))) unsigned char lb[2][3][TNB_STAGE * ROWB];
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+  const int mq = wv & 1, nh = wv >> 1;
+  const int mblk = tnb_mblk(blockIdx.x, nblk), chunk = tnb_chunk(blockIdx.x, nblk);
+  if (chunk >= nchunk) return;
+  const size_t nstages = (R + TNB_STAGE - 1) / TNB_STAGE;
+  const size_t s_begin = (size_t)chunk * stages_per_wg;
+  const size_t s_end = (s_begin + stages_per_wg < nstages) ? s_begin + stages_per_wg : nstages;
+  const int n = s_begin < s_end ? (int)(s_end - s_begin) : 0;
+#ifdef FASTGRNN_DIAG_STAMPS
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
+
+  // ---- requests: buffer loads.  A stage's rows of one operand are one resource descriptor -- base = the stage's first
+  // row, size = its valid rows, so rows beyond R read as zero without a comparison -- built in scalar registers; a lane
+  // keeps ONE loop-invariant byte offset per operand and piece j adds a scalar offset.
+  f32x4 sv[VQ];                                      // sv[0..VA) pieces of A, sv[VA..VQ) pieces of B
+  const unsigned va_off = (unsigned)(tid / (MB / 4)) * (unsigned)lda * 4u + (unsigned)(tid % (MB / 4)) * 16u;
+  const unsigned vb_off = (unsigned)(tid / (N / 4)) * (unsigned)ldb * 4u + (unsigned)(tid % (N / 4)) * 16u;
+  struct Desc { __amdgpu_buffer_rsrc_t a, b; };
+  auto desc_of = [&](int i) __attribute__((always_inline)) {   // stage s_begin + min(i, n - 1)
+    const size_t r0 = (s_begin + (size_t)(i < n ? i : n - 1)) * TNB_STAGE;
+    const unsigned rows = R - r0 < (size_t)TNB_STAGE ? (unsigned)(R - r0) : (unsigned)TNB_STAGE;   // >= 1
+    const float* bb = r0 < shiftB ? B0 + r0 * (size_t)ldb : B1 + (r0 - shiftB) * (size_t)ldb;
+    Desc d;
+    d.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + r0 * (size_t)lda + mblk * MB), 0,
+                                            (int)((rows - 1) * (unsigned)lda * 4u + MB * 4u), 0x00020000);
+    d.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb), 0, (int)((rows - 1) * (unsigned)ldb * 4u + N * 4u), 0x00020000);
+    return d;
+  };
+  auto request = [&](const Desc& d, int j) __attribute__((always_inline)) {
+    if (j < VA)
+      sv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.a, (int)va_off, (int)((unsigned)(j * (NP / (MB / 4))) * (unsigned)lda * 4u), 0));
+    else
+      sv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.b, (int)vb_off, (int)((unsigned)((j - VA) * (NP / (N / 4))) * (unsigned)ldb * 4u), 0));
+  };
+  // LDS address of piece j in plane 0 of buffer 0
+  const unsigned la0 = (unsigned)(size_t)&la[0][0][0], lb0 = (unsigned)(size_t)&lb[0][0][0];
+  const unsigned pa_off = (unsigned)(tid / (MB / 4)) * ROWA + (unsigned)(tid % (MB / 4)) * 8u;
+  const unsigned pb_off = (unsigned)(tid / (N / 4)) * ROWB + (unsigned)(tid % (N / 4)) * 8u;
+  // (buf: the lane's plane-0 addresses of pieces 0 in the buffer written to)
+  auto put_piece = [&](unsigned char* pa, unsigned char* pb, int j, const uint2 q0, const uint2 q1, const uint2 q2) __attribute__((always_inline)) {
+    unsigned char* p0;
+    int plane;
+    if (j < VA) { p0 = pa + j * (NP / (MB / 4)) * ROWA; plane = TNB_STAGE * ROWA; }
+    else { p0 = pb + (j - VA) * (NP / (N / 4)) * ROWB; plane = TNB_STAGE * ROWB; }
+    *reinterpret_cast<uint2*>(p0) = q0;
+    *reinterpret_cast<uint2*>(p0 + plane) = q1;
+    *reinterpret_cast<uint2*>(p0 + 2 * plane) = q2;
+  };
+  constexpr unsigned BUFA = 3 * TNB_STAGE * ROWA, BUFB = 3 * TNB_STAGE * ROWB;   // bytes per buffer
+
+  f32x4 acc[4][NH];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < NH; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned trA = la0 + (8 * g + q) * ROWA + (mq * 64 + 4 * pp) * 2;
+  const unsigned trB = lb0 + (8 * g + q) * ROWB + (nh * NH * 16 + 4 * pp) * 2;
+
+  if (n > 0) {
+    const Desc d0 = desc_of(0), d1 = desc_of(1);
+#pragma unroll
+    for (int j = 0; j < VQ; ++j) request(d0, j);
+#pragma unroll
+    for (int j = 0; j < VQ; ++j) {
+      uint2 q0, q1, q2;
+      split_quad(sv[j], q0, q1, q2);
+      put_piece(&la[0][0][0] + pa_off, &lb[0][0][0] + pb_off, j, q0, q1, q2);
+    }
+#pragma unroll
+    for (int j = 0; j < VQ; ++j) request(d1, j);
+    lds_barrier();
+  }
+  // stage i: products from buffer i & 1; between them the planes of stage i + 1 (waiting in sv) into the other buffer,
+  // each piece re-requested for stage i + 2 as soon as it is split.  Requests and plane writes are unconditional (the
+  // last stages re-request / re-publish the last stage): no branch between LDS writes and loads (second rule of
+  // DESIGN.md 4.0).
+  for (int i = 0; i < n; ++i) {
+    const unsigned par = (unsigned)(i & 1);
+    const unsigned oa = par * BUFA, ob = par * BUFB;
+    unsigned char* const wpa = &la[0][0][0] + pa_off + (par ^ 1u) * BUFA;
+    unsigned char* const wpb = &lb[0][0][0] + pb_off + (par ^ 1u) * BUFB;
+    SPLIT_STAMP(0)
+    const Desc dn = desc_of(i + 2);
+    Frag3 Af[4], Bf[NH];
+    auto read_b = [&](int c, Frag3& F) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.p[p] = tr_frag(trB + ob + p * (TNB_STAGE * ROWB) + c * 32, ROWB);
+    };
+    read_b(0, Bf[0]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Af[a].p[p] = tr_frag(trA + oa + p * (TNB_STAGE * ROWA) + a * 32, ROWA);
+    __builtin_amdgcn_sched_barrier(0);
+    uint2 q0, q1, q2;
+    auto split_one_pair = [&](int pr) __attribute__((always_inline)) {   // pair pr = values 2 * (pr & 1) .. + 1 of piece pr / 2
+      const int j = pr >> 1;
+      if (pr & 1) {
+        split_pair(sv[j][2], sv[j][3], q0.y, q1.y, q2.y);
+        asm volatile("" : "+v"(q0.y), "+v"(q1.y), "+v"(q2.y));
+        put_piece(wpa, wpb, j, q0, q1, q2);
+        request(dn, j);
+      } else {
+        split_pair(sv[j][0], sv[j][1], q0.x, q1.x, q2.x);
+        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x));
+      }
+    };
+    // the first PRE pairs while the fragment reads above are under way (the matrix pipe has nothing to do until they land)
+#pragma unroll
+    for (int pr = 0; pr < PRE; ++pr) split_one_pair(pr);
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(1)
+    constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};   // mfma6's terms in its order
+#pragma unroll
+    for (int c = 0; c < NH; ++c) {
+      if (c + 1 < NH) {                              // tile c + 1's B fragments, one tile ahead.  Every tile of the stage
+        read_b(c + 1, Bf[c + 1]);                    // has registers of its own (a lone wave has them): no fragment
+        __builtin_amdgcn_sched_barrier(0);           // register is written while an MFMA of the stage may still read it
+      }
+      // 24 MFMAs (four m-tiles interleaved: consecutive ones are independent) and PPT value pairs of the next stage
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][c] = mfma_bf16(Af[a].p[TA[t]], Bf[c].p[TB[t]], acc[a][c]);
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) split_one_pair(PRE + c * PPT + k);
+#pragma unroll
+      for (int k = 0; k < 24; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (PPT >= 3 || k % 4 != 3) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        if (k % 8 == 7) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                // every MFMA of the stage has retired before its fragments are replaced
+      float touch = 0.f;                             // (the last tile's four chains: the scheduler orders them freely; a
+#pragma unroll                                       // scheduling barrier separates the tiles)
+      for (int a = 0; a < 4; ++a) touch += acc[a][NH - 1][0];
+      completion_read(touch);
+#pragma unroll
+      for (int c = 0; c < NH; ++c) asm volatile("" :: "v"(Bf[c].p[0]), "v"(Bf[c].p[1]), "v"(Bf[c].p[2]));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(Af[a].p[0]), "v"(Af[a].p[1]), "v"(Af[a].p[2]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_STAMP(2)
+    lds_barrier();                                   // stage i consumed, stage i + 1 published
+  }
+#ifdef FASTGRNN_DIAG_STAMPS
+  if (blockIdx.x == 7 && l == 0) { for (int k = 0; k < 8; ++k) g_sdiag[wv][k] = dsum[k]; }
+#endif
+  float* pc = part + ((size_t)chunk * nblk + mblk) * MB * N;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < NH; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pc[(size_t)((mq * 4 + a) * 16 + 4 * g + r) * N + (nh * NH + c) * 16 + (l & 15)] = acc[a][c][r];
+}
+
 // C[(mblk*128 + m) * ldc + n] = sum over row chunks of part[chunk][mblk][m][n], fixed order
 __global__ __launch_bounds__(1024) void tn_big_reduce(int nchunk, int nblk, int N, const float* __restrict__ part,
                                                       float* __restrict__ C, int ldc) {
@@ -439,11 +650,18 @@ int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float
   if (!tn_gemm_big_supported(M, N)) return FASTGRNN_ERR_UNSUPPORTED;
   int spw;
   const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
-  dim3 grid(nch * nblk);
+  dim3 grid(((nch + 7) / 8) * 8 * nblk);
 #define TNB_CASE(n) \
-  if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, nblk, A, lda, B0, B1, shiftB, ldb, part);
-  TNB_CASE(32) TNB_CASE(64) TNB_CASE(128) TNB_CASE(256)
+  if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
+  TNB_CASE(32) TNB_CASE(64) TNB_CASE(128)
 #undef TNB_CASE
+  if (N == 256) {
+    // (a stage of tn_gemm_w4 takes its rows of B from ONE source)
+    if (shiftB == 0 || shiftB >= R || shiftB % TNB_STAGE == 0)
+      hipLaunchKernelGGL((tn_gemm_w4<16, TNW4_PRE>), grid, dim3(256), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
+    else
+      hipLaunchKernelGGL((tn_gemm_big<16>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
+  }
   const int total = M * N;
   hipLaunchKernelGGL(tn_big_reduce, dim3((total + 63) / 64), dim3(1024), 0, s, nch, nblk, N, (const float*)part, C, ldc);
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
