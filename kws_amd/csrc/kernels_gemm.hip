@@ -212,7 +212,9 @@ __device__ __forceinline__ int tnb_mblk(int bid, int nblk) { return (bid >> 3) %
 #define TNW4_PRE 0                                // tn_gemm_w4: value pairs split before a stage's first MFMA (A/B knob)
 #endif
 
-template <int NT>
+// PERIODIC: row r of B is B0[r / shiftB] where r is a multiple of shiftB, else B1[r - 1] (H_prev of batch-major
+// sequences: shiftB = T; the first step of every utterance reads h0, the others the row before their own).
+template <int NT, bool PERIODIC = false>
 __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, int nchunk, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B0, const float* __restrict__ B1,
                                                    size_t shiftB, int ldb, float* __restrict__ part) {
@@ -258,7 +260,13 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     for (int j = 0; j < VB; ++j) {
       const int idx = tid + 512 * j, row = idx / (N / 4), c4 = idx % (N / 4);
       const size_t r = r0 + row;
-      const float* src = r < shiftB ? B0 + r * (size_t)ldb : B1 + (r - shiftB) * (size_t)ldb;   // H_prev: rows of t = 0 are h0
+      const float* src;
+      if (PERIODIC) {                                // (R < 2^32: the workspace that holds A is below 4 GB)
+        const unsigned ru = (unsigned)r, qd = ru / (unsigned)shiftB;
+        src = (qd * (unsigned)shiftB == ru) ? B0 + (size_t)qd * ldb : B1 + (size_t)(ru - 1u) * ldb;
+      } else {
+        src = r < shiftB ? B0 + r * (size_t)ldb : B1 + (r - shiftB) * (size_t)ldb;   // H_prev: rows of t = 0 are h0
+      }
       vb[j] = (idx < TNB_STAGE * N / 4 && r < R) ? ld4(src + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -635,6 +643,17 @@ static inline int tnb_chunks(size_t R, int nblk, int* spw) {
   if (want > nstages) want = nstages;
   *spw = (int)((nstages + want - 1) / want);
   return (int)((nstages + *spw - 1) / *spw);
+}
+
+int tn_gemm_big_run_periodic(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t period,
+                             int ldb, float* part, float* C, int ldc, hipStream_t s) {
+  if (N != 256 || (M != 128 && M != 256) || period == 0 || R >= ((size_t)1 << 32)) return FASTGRNN_ERR_UNSUPPORTED;
+  int spw;
+  const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
+  dim3 grid(((nch + 7) / 8) * 8 * nblk);
+  hipLaunchKernelGGL((tn_gemm_big<16, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, period, ldb, part);
+  hipLaunchKernelGGL(tn_big_reduce, dim3((M * N + 63) / 64), dim3(1024), 0, s, nch, nblk, N, (const float*)part, C, ldc);
+  return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
 
 bool tn_gemm_big_supported(int M, int N) { return (M == 128 || M == 256) && (N == 32 || N == 64 || N == 128 || N == 256); }

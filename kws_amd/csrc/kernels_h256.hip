@@ -45,11 +45,15 @@ constexpr int SLAB2 = 576;                      // floats per workgroup: d_bz[25
 // front of this launch, and the scan reads P(t) where it otherwise runs its W.x MFMAs (as the H = 128 wide layers do).
 template <int GATE, int AUX, bool RAGGED, int MODE, bool PREIN = false>
 __global__ __launch_bounds__(512) void fwd_scan_h256(
-    int Tn, int B, const float* __restrict__ x, const float* __restrict__ h0,
+    int Tn, int B, unsigned hsT, unsigned hsB, unsigned xsT, unsigned xsB,
+    const float* __restrict__ x, const float* __restrict__ h0,
     const float* __restrict__ w, const float* __restrict__ u,
     const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ hs, float* __restrict__ zs, float* __restrict__ cs, unsigned* __restrict__ flags) {
+  // hsT / hsB: element strides of one step / one utterance in hs, zs, cs (and in P under PREIN, whose rows follow the
+  // frames' order); xsT / xsB: the same for x.  Time-major: (B*256, 256) and (B*32, 32); FASTGRNN_FLAG_BATCH_MAJOR:
+  // (256, T*256) and (32, T*32) -- rnn.py:812-813 transposes instead.
   constexpr bool F16H = MODE == 1;
   if (MODE == 2 && flags[blockIdx.x] == 0u) return;  // (whole workgroup; no barrier has been passed)
   // One byte array carved per path (static LDS is the maximum over both):
@@ -188,23 +192,23 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     *reinterpret_cast<unsigned short*>(xpl + PLX2 + off) = s1;
     *reinterpret_cast<unsigned short*>(xpl + 2 * PLX2 + off) = s2;
   };
-  const float* xlane = x + (size_t)xbc * F2 + xf;          // this lane's value of frame t: xlane[t * B * F]
-  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * B * F2]; };
+  const float* xlane = x + (size_t)xbc * xsB + xf;         // this lane's value of frame t: xlane[t * xsT]
+  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * xsT]; };
   // PREIN: this lane's eight values of P(t) (rows of lanes beyond a ragged batch: the last utterance's)
-  const float* plane = x + (size_t)bc * H2 + n0;
+  const float* plane = x + (size_t)bc * hsB + n0;
   auto load_p = [&](int t, f32x4 (&q)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) q[mt] = ld4(plane + (size_t)t * B * H2 + 16 * mt);
+    for (int mt = 0; mt < 2; ++mt) q[mt] = ld4(plane + (size_t)t * hsT + 16 * mt);
   };
-  const unsigned lane_hs = (unsigned)b * H2 + n0;
+  const unsigned lane_hs = (unsigned)b * hsB + n0, lane_bh = (unsigned)b * H2 + n0;   // in a sequence / in a [B,H] tensor
   auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
     if (valid) {
-      float* ho = hs_last ? hs + lane_hs : hs + (size_t)t * B * H2 + lane_hs;
+      float* ho = hs_last ? hs + lane_bh : hs + (size_t)t * hsT + lane_hs;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) st4(ho + 16 * mt, hown[mt]);
       if (AUX == 2) {
-        float* po = zs + (size_t)t * B * H2 + lane_hs;
+        float* po = zs + (size_t)t * hsT + lane_hs;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) st4(po + 16 * mt, aux[mt]);
       }
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
         zq[r] = z; cq[r] = c;
       }
       if (AUX == 1 && valid) {                       // reference operator outputs: stored at once
-        const size_t o = (size_t)t * B * H2 + lane_hs + 16 * mt;
+        const size_t o = (size_t)t * hsT + lane_hs + 16 * mt;
         st4(zs + o, zq); st4(cs + o, cq);
       }
       aux_prev[mt] = pre;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
 // gradient of the last state alone.
 template <int GATE, bool PREACT, bool RAGGED>
 __global__ __launch_bounds__(512) void bwd_scan_h256(
-    int Tn, int B, int mode, const float* __restrict__ ghs, const float* __restrict__ hs,
+    int Tn, int B, int mode, unsigned hsT, unsigned hsB, const float* __restrict__ ghs, const float* __restrict__ hs,
     const float* __restrict__ aux0, const float* __restrict__ aux1, const float* __restrict__ h0,
     const float* __restrict__ u, const float* __restrict__ bz, const float* __restrict__ bh,
     const float* __restrict__ zeta, const float* __restrict__ nu,
@@ -440,31 +444,36 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   float pz = 0.f, pn = 0.f, pz_c = 0.f, pn_c = 0.f;   // d_zeta / d_nu partial sums, compensated
 
   // Addresses: a wave-uniform step base (scalar registers) + a 32-bit lane offset (the host rejects B*H*4 >= 2^31)
-  const unsigned lane_c = ((unsigned)bc * H2 + n0) * 4u, lane_v = ((unsigned)b * H2 + n0) * 4u;   // BYTE offsets
+  // hsT / hsB: element strides of one step / one utterance in grad_hs, hs, the saved tensors AND the d_pre workspace,
+  // whose rows follow the sequences' order (time-major: B*256, 256; FASTGRNN_FLAG_BATCH_MAJOR: 256, T*256) so that the
+  // GEMMs behind this scan pair its rows with the caller's rows of x and hs as they lie.
+  const unsigned lane_c = ((unsigned)bc * hsB + n0) * 4u, lane_v = ((unsigned)b * hsB + n0) * 4u;   // BYTE offsets in a sequence
+  const unsigned lane_c0 = ((unsigned)bc * H2 + n0) * 4u, lane_v0 = ((unsigned)b * H2 + n0) * 4u;   // ... in a [B,H] tensor
   auto ldg = [](const float* base, unsigned off) __attribute__((always_inline)) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
   };
-  const unsigned dp_step = valid ? (unsigned)B * H2 * 4u : 0u;
+  const unsigned dp_step = valid ? hsT * 4u : 0u;
   const unsigned dp_off = valid ? lane_v : (((unsigned)Tn * (unsigned)B + i) * H2 + n0) * 4u;
   auto stg = [](float* base, unsigned off, f32x4 v) __attribute__((always_inline)) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + off) = v;
   };
   struct EwOps { f32x4 g[2], a0[2], a1[2], h[2]; };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
-    const size_t step = (size_t)t * B * H2;                                  // uniform
+    const size_t step = (size_t)t * hsT;                                     // uniform
     const float* gt = g_last ? ghs : ghs + step;
     const float* p0 = aux0 + step;
     const float* p1 = PREACT ? aux0 : aux1 + step;
-    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)B * H2);         // .cu:478-481
+    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)hsT);            // .cu:478-481
+    const unsigned lane_g = g_last ? lane_c0 : lane_c, lane_h = (t == 0) ? lane_c0 : lane_c;
     const bool g_zero = (g_last && t != Tn - 1) || (RAGGED && !valid);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero: gg, d_pre and
       // every sum they enter stay exactly zero for them)
-      e.g[mt] = g_zero ? z4 : ldg(gt, lane_c + 64u * mt);
+      e.g[mt] = g_zero ? z4 : ldg(gt, lane_g + 64u * mt);
       e.a0[mt] = ldg(p0, lane_c + 64u * mt);
       if (!PREACT) e.a1[mt] = ldg(p1, lane_c + 64u * mt);
-      e.h[mt] = ldg(ht, lane_c + 64u * mt);
+      e.h[mt] = ldg(ht, lane_h + 64u * mt);
     }
   };
 
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   // ---- flush ---------------------------------------------------------------------------------
   if (valid) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) stg(d_h0, lane_v + 64u * mt, dh[mt]);
+    for (int mt = 0; mt < 2; ++mt) stg(d_h0, lane_v0 + 64u * mt, dh[mt]);
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -720,8 +729,13 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
     rows_gemm((size_t)d.T * d.B, H2, d.F, false, x, (const float*)p.w, P, false, false, s);
     x = P;
   }
+  // strides of the sequences (elements): FASTGRNN_FLAG_BATCH_MAJOR lays hs / zs / cs and x out as [B,T,*]; the
+  // workspace copy of [B,F,T] frames is time-major whatever the flag says; P's rows follow the order of x's
+  const bool bm = (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) != 0, xbm = bm && !(d.flags & FASTGRNN_FLAG_X_BFT);
+  const unsigned hsT = bm ? H2 : (unsigned)d.B * H2, hsB = bm ? (unsigned)d.T * H2 : H2;
+  const unsigned xsT = xbm ? F2 : (unsigned)d.B * F2, xsB = xbm ? (unsigned)d.T * F2 : F2;
   auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, (const float*)x, (const float*)h0, (const float*)p.w,
+    hipLaunchKernelGGL(kern, grid, block, 0, s, d.T, d.B, hsT, hsB, xsT, xsB, (const float*)x, (const float*)h0, (const float*)p.w,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)hs, (float*)zs, (float*)cs, flags);
   };
@@ -757,8 +771,10 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
   float* part = (float*)(base + L.part); float* dpre = (float*)(base + L.dpre); float* tn = (float*)(base + L.tn);
   const int nwg = (d.B + 15) / 16;
   const bool ragged = (d.B % 16) != 0, preact = (d.flags & FASTGRNN_FLAG_SAVE_PREACT) != 0;
+  const bool bm = (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) != 0;
+  const unsigned hsT = bm ? H2 : (unsigned)d.B * H2, hsB = bm ? (unsigned)d.T * H2 : H2;
   auto go = [&](auto kern) __attribute__((always_inline)) {
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 0, s, d.T, d.B, (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 2 : 0,
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), 0, s, d.T, d.B, (d.flags & FASTGRNN_FLAG_GRAD_LAST) ? 2 : 0, hsT, hsB,
                        (const float*)ghs, (const float*)hs, (const float*)a0, (const float*)a1, (const float*)h0,
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_h0, dpre, part);
@@ -769,7 +785,9 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
                      (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
   const size_t TB = (size_t)d.T * d.B;
   // dU = d_pre^T . H_prev (rows of t = 0 are h0, the rest hs[t-1]);  dW = d_pre^T . X   (.cu:539-540 over all steps)
-  tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
+  // (batch-major: row b*T + t of d_pre pairs with hs row b*T + t - 1, every T-th row with h0[b])
+  if (bm) tn_gemm_big_run_periodic(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.T, H2, tn, (float*)g.d_u, H2, s);
+  else tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
   const bool bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
   float* xtm = (float*)(base + L.xtm);
   if (bft) bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
@@ -790,11 +808,13 @@ bool h256_shape(const fastgrnn_desc& d) {
   return d.w_rank == 0 && d.u_rank == 0 && d.H == H2 && (d.F == F2 || d.F == 64 || d.F == 128) && d.B < (1 << 21);
 }
 
-// time-major fp32 sequences, every gate, both saved-tensor contracts, full or last-state outputs / gradients
+// fp32 sequences, time- or batch-major, every gate, both saved-tensor contracts, full or last-state outputs / gradients
 bool h256_supported(const fastgrnn_desc& d, int direction) {
   if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
-  if (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) return false;
   if (d.F != F2 && (d.flags & FASTGRNN_FLAG_X_BFT)) return false;      // (the loader's [B,F,T] batches: 32 features)
+  // batch-major sequences: two-stride rows in both scans; the backward's d_pre rows then follow [B,T], which a
+  // time-major workspace copy of [B,F,T] frames would not match
+  if (direction == 1 && (d.flags & FASTGRNN_FLAG_BATCH_MAJOR) && (d.flags & FASTGRNN_FLAG_X_BFT)) return false;
   // 32-bit byte offsets inside the d_pre workspace, its 16 sink rows included
   if (((double)d.T * d.B + 16.0) * H2 * 4.0 >= 4294967296.0) return false;
   if (direction == 0 && (d.flags & FASTGRNN_FLAG_SAVE_PREACT) && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;

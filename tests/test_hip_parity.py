@@ -301,7 +301,7 @@ def _copy_params(m, p):
 
 
 @pytest.mark.parametrize("batch_first", [False, True])
-@pytest.mark.parametrize("lowrank", [False, True, "config4"])
+@pytest.mark.parametrize("lowrank", [False, True, "config4", "dense256", "dense256f64"])
 def test_module_autograd_matches_cpu_port(batch_first, lowrank):
     """FastGRNNCUDA (rnn.py:738-826) forward+autograd vs the torch CPU port of
     FastGRNNCell + BaseRNN loop (the reference's CPU path)."""
@@ -311,6 +311,12 @@ def test_module_autograd_matches_cpu_port(batch_first, lowrank):
     rw = ru = 8 if lowrank else None
     if lowrank == "config4":             # BASELINE configs[3] shape: the low-rank split-precision kernels
         H, rw, ru = 256, 16, 16
+    if lowrank in ("dense256", "dense256f64"):   # the default stack's first layer (trainingConfig.py:12-15, :36): the
+        F = 64 if lowrank == "dense256f64" else F    # H = 256 scans, [B,T,.] indexed in place under batch_first
+        H, rw, ru, lowrank = 256, None, None, False
+    if H == 256 and rw is None and batch_first:
+        from kws_amd import _lib as _l
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_l.FLAG_SAVE_PREACT | _l.FLAG_BATCH_MAJOR) == 2
     cell = FastGRNNCellPort(F, H, wRank=rw, uRank=ru)
     with torch.no_grad():
         cell.bias_gate.add_(0.3 * torch.randn_like(cell.bias_gate)); cell.zeta.fill_(0.4); cell.nu.fill_(-3.0)

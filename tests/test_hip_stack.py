@@ -146,21 +146,40 @@ def test_stack_layer_batch_major_and_last_state_contracts(F, H):
     h0 = _t((0.5 * rng.standard_normal((B, H))).astype(np.float32))
     G = _t(rng.standard_normal((T, B, H)).astype(np.float32))
     outs, gr = _run(x, h0, G, p, preact=True)
-    if H == 128:
-        # (the H = 256 scans are time-major only: their dU GEMM reads H_prev as "hs shifted down by B rows";
-        # FastGRNNCUDA(batch_first=True) transposes for them as the reference does, rnn.py:812-813)
-        xb, Gb = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
-        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
-        outs_b, gr_b = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR, preact=True)
-        assert torch.equal(outs_b[0].transpose(0, 1), outs[0]) and torch.equal(outs_b[1].transpose(0, 1), outs[1])
-        assert torch.equal(gr_b[0].transpose(0, 1), gr[0])
-        for k, (a, b) in enumerate(zip(gr[1:8], gr_b[1:8])):
-            if k == 5:     # d_w: the TN GEMM sums the rows in memory order, which differs between the two layouts
-                assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
-            else:
-                assert torch.equal(a, b), k
-    else:
-        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) != 2
+    # (round 3: the H = 256 scans index [B,T,.] in place too -- two-stride rows, the d_pre workspace in the sequences'
+    # row order, and a dU GEMM that takes every T-th row of H_prev from h0)
+    xb, Gb = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=0, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=_lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR) == 2
+    outs_b, gr_b = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR, preact=True)
+    assert torch.equal(outs_b[0].transpose(0, 1), outs[0]) and torch.equal(outs_b[1].transpose(0, 1), outs[1])
+    assert torch.equal(gr_b[0].transpose(0, 1), gr[0])
+    for k, (a, b) in enumerate(zip(gr[1:8], gr_b[1:8])):
+        if k == 5 or (k == 6 and H == 256):   # d_w (d_u): the TN GEMM sums the rows in memory order, which differs between the layouts
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), k
+        else:
+            assert torch.equal(a, b), k
+    if H == 256:
+        # the reference operator's own contract (z_s and h_prime_s saved) in place as well, and the last-state pair
+        outs_z, gr_z = _run(x, h0, G, p)
+        outs_zb, gr_zb = _run(xb, h0, Gb, p, flags=_lib.FLAG_BATCH_MAJOR)
+        for a, b in zip(outs_z, outs_zb):
+            assert torch.equal(b.transpose(0, 1), a)
+        assert torch.equal(gr_zb[0].transpose(0, 1), gr_z[0]) and torch.equal(gr_zb[5], gr_z[5])
+        for k in (6, 7):
+            assert float((gr_zb[k] - gr_z[k]).abs().max()) <= 2e-6 * max(1.0, float(gr_z[k].abs().max())), k
+        fb = _lib.FLAG_SAVE_PREACT | _lib.FLAG_BATCH_MAJOR | _lib.FLAG_GRAD_LAST
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, direction=1, flags=fb) == 2
+        got = fastgrnn_cuda.backward_unroll(G[-1].contiguous(), xb, outs_b[0], P["zeta"], P["nu"], P["w"], P["u"], outs_b[1],
+                                            outs_b[1], h0, e, e, e, e, 0, flags=fb, bias_gate=P["bias_gate"],
+                                            bias_update=P["bias_update"])
+        Gl0 = torch.zeros_like(G); Gl0[-1] = G[-1]
+        want = fastgrnn_cuda.backward_unroll(Gl0, x, outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[1], h0, e, e,
+                                             e, e, 0, flags=_lib.FLAG_SAVE_PREACT, bias_gate=P["bias_gate"],
+                                             bias_update=P["bias_update"])
+        assert torch.equal(got[0].transpose(0, 1), want[0]) and torch.equal(got[5], want[5])
+        for k in (6, 7):
+            assert float((got[k] - want[k]).abs().max()) <= 2e-6 * max(1.0, float(want[k].abs().max())), k
     # last-state gradient
     Gl = torch.zeros_like(G); Gl[-1] = G[-1]
     fl = _lib.FLAG_SAVE_PREACT
