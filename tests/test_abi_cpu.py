@@ -124,11 +124,14 @@ def test_last_state_flags_are_refused_where_no_kernel_implements_them(lib):
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_GRAD_LAST, **lr)), 1) != 2      # reference contract
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(flags=_lib.FLAG_HS_LAST, **lr)), 0) == 2
     # the other factorised H=256 cells run on the dense H=256 kernels (factors multiplied out per call): path 2, with
-    # that path's own limits (no batch-major / [B,F,T] / bf16); ranks above H have no fast path
+    # that path's own limits (batch-major since round 3; no bf16, no [B,F,T] frames beside batch-major sequences in the
+    # backward); ranks above H have no fast path
     for w_rank, u_rank in ((32, 32), (16, 0), (0, 16), (17, 16)):
         d = _desc(H=256, w_rank=w_rank, u_rank=u_rank, flags=_lib.FLAG_GRAD_LAST | _lib.FLAG_SAVE_PREACT)
         assert lib.fastgrnn_hip_kernel_path(C.byref(d), 1) == 2
         d = _desc(H=256, w_rank=w_rank, u_rank=u_rank, flags=_lib.FLAG_BATCH_MAJOR | _lib.FLAG_SAVE_PREACT)
+        assert lib.fastgrnn_hip_kernel_path(C.byref(d), 1) == 2
+        d = _desc(H=256, w_rank=w_rank, u_rank=u_rank, flags=_lib.FLAG_BATCH_MAJOR | _lib.FLAG_X_BFT | _lib.FLAG_SAVE_PREACT)
         assert lib.fastgrnn_hip_kernel_path(C.byref(d), 1) != 2
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=256, w_rank=300, u_rank=8, flags=_lib.FLAG_SAVE_PREACT)), 1) != 2
     assert lib.fastgrnn_hip_kernel_path(C.byref(_desc(H=64, flags=_lib.FLAG_HS_LAST)), 0) != 2

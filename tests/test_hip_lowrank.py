@@ -181,9 +181,10 @@ def test_module_lowrank_uses_the_layout_flags(kind):
         assert torch.equal(a.grad, b.grad), n
 
 
+@pytest.mark.parametrize("bm", [False, True], ids=["tm", "bm"])
 @pytest.mark.parametrize("rw,ru,B,preact", [(32, 32, 37, True), (32, 32, 64, False), (16, None, 48, True), (None, 16, 33, True),
                                             (64, 8, 16, True), (17, 16, 21, False)])
-def test_other_factorised_cells_run_on_the_dense_kernels(rw, ru, B, preact):
+def test_other_factorised_cells_run_on_the_dense_kernels(rw, ru, B, preact, bm):
     """Ranks above 16 and cells with only W or only U factorised (rnn.py:783-798): the factors are multiplied out per
     call, the dense H=256 scans run, the dense gradients are projected onto the factors (what the reference's CUDA
     operator does for every low-rank cell, .cu:353-362,546-555).  Against the fp64 oracle's FACTORISED evaluation."""
@@ -196,15 +197,19 @@ def test_other_factorised_cells_run_on_the_dense_kernels(rw, ru, B, preact):
     x = rng.standard_normal((T, B, F)).astype(np.float32)
     h0 = (0.5 * rng.standard_normal((B, H))).astype(np.float32)
     G = rng.standard_normal((T, B, H)).astype(np.float32)
-    fl = SAVE_PREACT if preact else 0
+    fl = (SAVE_PREACT if preact else 0) | (BATCH_MAJOR if bm else 0)     # bm: [B,T,.] sequences indexed in place
     for direction in (0, 1):
         assert fastgrnn_cuda.kernel_path(T, B, F, H, rw or 0, ru or 0, 0, direction=direction, flags=fl) == 2
-    outs = fastgrnn_cuda.forward_unroll(_t(x), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), 0,
+    lay = (lambda a: np.ascontiguousarray(a.transpose(1, 0, 2))) if bm else (lambda a: a)
+    outs = fastgrnn_cuda.forward_unroll(_t(lay(x)), P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], _t(h0), 0,
                                         P["w1"], P["w2"], P["u1"], P["u2"], flags=fl)
     assert len(outs) == (2 if preact else 3)
-    gr = fastgrnn_cuda.backward_unroll(_t(G), _t(x), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
+    gr = fastgrnn_cuda.backward_unroll(_t(lay(G)), _t(lay(x)), outs[0], P["zeta"], P["nu"], P["w"], P["u"], outs[1], outs[-1], _t(h0),
                                        P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=fl,
                                        bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+    if bm:
+        outs = [o.transpose(0, 1) for o in outs]
+        gr = [gr[0].transpose(0, 1)] + list(gr[1:])
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     hs_o, zs_o, cs_o = O.unroll_forward(x.astype(np.float64), p64, h0.astype(np.float64))
     assert (np.abs(outs[0].cpu().numpy() - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 1e-5
