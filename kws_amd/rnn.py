@@ -61,6 +61,8 @@ class FastGRNNFunction(Function):
 
 
 _unroll_decisions = {}
+_zero_states = {}        # (B, H, dtype, device) -> the default h0
+_inference_ok = {}       # call signature -> "the hs-only forward is on kernel path 2"
 
 
 class FastGRNNUnrollFunction(Function):
@@ -386,19 +388,56 @@ class FastGRNNCUDA(nn.Module):
         if hiddenState is None:
             # bf16 sequences (BASELINE config "bf16 with fp32 master grads") keep an fp32 state and parameters
             hdt = torch.float32 if input.dtype == torch.bfloat16 else input.dtype
-            hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=hdt, device=input.device)
+            # (the default state is read-only to every kernel and never handed out: one tensor per shape instead of a
+            # fill launch per call)
+            zkey = (nbatch, self._hidden_size, hdt, input.device)
+            hiddenState = None if torch.is_inference_mode_enabled() else _zero_states.get(zkey)
+            if hiddenState is None:
+                hiddenState = torch.zeros([nbatch, self._hidden_size], dtype=hdt, device=input.device)
+                if not torch.is_inference_mode_enabled():   # (an inference tensor could not be saved for a backward later)
+                    if len(_zero_states) >= 16:
+                        _zero_states.clear()
+                    _zero_states[zkey] = hiddenState
         if not hiddenState.is_cuda:
             hiddenState = hiddenState.to(self.device)
         if last_state and not torch.is_grad_enabled():
             out = self._last_state_inference(input, hiddenState, in_place)
             if out is not None:
                 return out
+        if not last_state and not torch.is_grad_enabled():
+            out = self._inference_forward(input, hiddenState, in_place)
+            if out is not None:
+                return out.transpose(0, 1) if (self.batch_first is True and not in_place) else out
         result = FastGRNNUnrollFunction.apply(input, self.bias_gate, self.bias_update, self.zeta, self.nu,
                                               hiddenState, self.W, self.U, self.W1, self.W2, self.U1, self.U2,
                                               self._gate_non_linearity, in_place, bool(last_state))
         if self.batch_first is True and not in_place and not last_state:
             return result.transpose(0, 1)
         return result
+
+    def _inference_forward(self, input, hiddenState, batch_major):
+        """hs alone when nothing will be differentiated (torch.no_grad()): no tensor is saved for a backward, so the
+        scan writes one [T,B,H] tensor instead of two.  None where the kernels have no such variant (the caller then
+        goes through the autograd function as before)."""
+        if not (input.is_cuda and input.is_contiguous() and input.dtype in (torch.float32, torch.bfloat16)):
+            return None
+        key = (input.shape, input.dtype, batch_major, self.W1.shape, self.U1.shape, self._gate_non_linearity)
+        ok = _inference_ok.get(key)
+        flags = _lib.FLAG_BATCH_MAJOR if batch_major else 0
+        if ok is None:
+            if batch_major:
+                Bn, Tn, Fn = input.shape
+            else:
+                Tn, Bn, Fn = input.shape
+            rw = self.W1.shape[0] if self.W1.numel() else 0
+            ru = self.U1.shape[0] if self.U1.numel() else 0
+            ok = _inference_ok[key] = fastgrnn_cuda.kernel_path(
+                Tn, Bn, Fn, self._hidden_size, rw, ru, self._gate_non_linearity, 2, input.dtype, 0, flags) == 2
+        if not ok:
+            return None
+        return fastgrnn_cuda.forward_unroll(input, self.W, self.U, self.bias_gate, self.bias_update, self.zeta, self.nu,
+                                            hiddenState.contiguous(), self._gate_non_linearity, self.W1, self.W2,
+                                            self.U1, self.U2, want_gates=False, flags=flags)[0]
 
     def _last_state_inference(self, input, hiddenState, batch_major):
         """h_T without writing hs[T,B,H] (FLAG_HS_LAST); None where the kernels cannot (other shapes / paths)."""

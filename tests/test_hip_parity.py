@@ -1044,3 +1044,24 @@ def test_model_tail_last_state_plus_head_matches_the_reference_chain():
         scale = max(1e-12, float(g_ref[n].abs().max()))
         assert float((p_.grad - g_ref[n]).abs().max()) / scale <= 2e-5, n
     assert float((x2.grad - x1.grad).abs().max()) / max(1e-12, float(x1.grad.abs().max())) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_module_forward_without_grad_saves_nothing_and_matches_the_training_forward(batch_first):
+    """Under torch.no_grad() the module runs the hs-only forward (no pre-activation written); same bits as the
+    training forward, also after a call under inference_mode (the cached default state must not be an inference tensor)."""
+    torch.manual_seed(3)
+    T, B, F, H = 17, 40, 32, 128
+    m = FastGRNNCUDA(F, H, batch_first=batch_first, device=DEV)
+    x = torch.randn((B, T, F) if batch_first else (T, B, F), device=DEV)
+    with torch.inference_mode():
+        hs_i = m(x).clone()
+    with torch.no_grad():
+        hs_n = m(x)
+    xg = x.clone().requires_grad_(True)
+    hs_t = m(xg)
+    assert hs_t.requires_grad and not hs_n.requires_grad
+    assert torch.equal(hs_n, hs_t.detach()) and torch.equal(hs_i, hs_n)
+    hs_t.square().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
