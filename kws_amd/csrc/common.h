@@ -88,11 +88,11 @@ int rows_gemm(size_t R, int N, int K, bool trans_w, const void* A, const float* 
               hipStream_t s);
 bool tn_gemm_big_supported(int M, int N);
 size_t tn_gemm_big_ws(size_t R, int M, int N);
-int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t shiftB,
-                    int ldb, float* part, float* C, int ldc, hipStream_t s);
+int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float* B0, const void* B1, size_t shiftB,
+                    int ldb, float* part, float* C, int ldc, hipStream_t s, bool bf_b = false);   // bf_b: B1 holds bf16
 // ... with row r of B = B0[r / period] where r is a multiple of period, else B1[r - 1] (N = 256 only)
-int tn_gemm_big_run_periodic(size_t R, int M, int N, const float* A, int lda, const float* B0, const float* B1, size_t period,
-                             int ldb, float* part, float* C, int ldc, hipStream_t s);
+int tn_gemm_big_run_periodic(size_t R, int M, int N, const float* A, int lda, const float* B0, const void* B1, size_t period,
+                             int ldb, float* part, float* C, int ldc, hipStream_t s, bool bf_b = false);
 
 // dense H = 256 / F = 32 scans (kernels_h256.hip), dispatched through split_supported / split_forward / split_backward
 bool h256_shape(const fastgrnn_desc& d);

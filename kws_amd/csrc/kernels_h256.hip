@@ -43,7 +43,8 @@ constexpr int SLAB2 = 576;                      // floats per workgroup: d_bz[25
 // trainingConfig.py:36, mfccProcessor.py:27-28; F = 128) -- W no longer fits beside U, and its product with the frames
 // has no recurrence in it: `x` is then P[T*B, 256] = X . W^T, written by the batched frame GEMM (kernels_gemm.hip) in
 // front of this launch, and the scan reads P(t) where it otherwise runs its W.x MFMAs (as the H = 128 wide layers do).
-template <int GATE, int AUX, bool RAGGED, int MODE, bool PREIN = false>
+// BF: FASTGRNN_BF16_IO -- x and hs are bf16 in HBM (P, the saved pre-activation, h0 and the state itself stay fp32).
+template <int GATE, int AUX, bool RAGGED, int MODE, bool PREIN = false, bool BF = false>
 __global__ __launch_bounds__(512) void fwd_scan_h256(
     int Tn, int B, unsigned hsT, unsigned hsB, unsigned xsT, unsigned xsB,
     const float* __restrict__ x, const float* __restrict__ h0,
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       }
     }
   };
-  auto publish_x = [&](int buf, float v) __attribute__((always_inline)) {
+  auto publish_x = [&](int buf, unsigned bits) __attribute__((always_inline)) {   // bits: as load_x returned them
+    const float v = BF ? bitsf(bits << 16) : bitsf(bits);
     unsigned short s0, s1, s2;
     split_one(v, s0, s1, s2);
     const unsigned off = (unsigned)(buf * 3 * PLX2 + xu * ROWX2 + xf * 2);
@@ -192,8 +194,13 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
     *reinterpret_cast<unsigned short*>(xpl + PLX2 + off) = s1;
     *reinterpret_cast<unsigned short*>(xpl + 2 * PLX2 + off) = s2;
   };
-  const float* xlane = x + (size_t)xbc * xsB + xf;         // this lane's value of frame t: xlane[t * xsT]
-  auto load_x = [&](int t) __attribute__((always_inline)) { return xlane[(size_t)t * xsT]; };
+  // this lane's value of frame t, as raw bits (a bf16 value is widened when it is published, not here: the conversion
+  // would wait for the load at once)
+  const char* xlane = reinterpret_cast<const char*>(x) + ((size_t)xbc * xsB + xf) * (BF ? 2 : 4);
+  auto load_x = [&](int t) __attribute__((always_inline)) -> unsigned {
+    if (BF) return (unsigned)*reinterpret_cast<const unsigned short*>(xlane + (size_t)t * xsT * 2);
+    return *reinterpret_cast<const unsigned*>(xlane + (size_t)t * xsT * 4);
+  };
   // PREIN: this lane's eight values of P(t) (rows of lanes beyond a ragged batch: the last utterance's)
   const float* plane = x + (size_t)bc * hsB + n0;
   auto load_p = [&](int t, f32x4 (&q)[2]) __attribute__((always_inline)) {
@@ -204,9 +211,12 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
   auto store_step = [&](int t, const f32x4* aux) __attribute__((always_inline)) {   // hown holds h_t
     if (hs_last && t != Tn - 1) return;               // (wave-uniform) the classifier reads h_T only: model.py:227
     if (valid) {
-      float* ho = hs_last ? hs + lane_bh : hs + (size_t)t * hsT + lane_hs;
+      const size_t eo = hs_last ? (size_t)lane_bh : (size_t)t * hsT + lane_hs;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) st4(ho + 16 * mt, hown[mt]);
+      for (int mt = 0; mt < 2; ++mt) {
+        if (BF) st4_bf16(reinterpret_cast<unsigned short*>(hs) + eo + 16 * mt, hown[mt]);
+        else st4(hs + eo + 16 * mt, hown[mt]);
+      }
       if (AUX == 2) {
         float* po = zs + (size_t)t * hsT + lane_hs;
 #pragma unroll
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
 
   __syncthreads();                                   // sbias staged; bf16 path: every wave's plane-2 fragments written
   publish_h(0);
-  float xnext = 0.f;
+  unsigned xnext = 0u;
   f32x4 pnext[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if (PREIN) {
     load_p(0, pnext);
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
   f32x4 aux_prev[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   for (int t = 0; t < Tn; ++t) {
     const int cur = H16 ? (t & 1) : 0, nxt = H16 ? (cur ^ 1) : 0;
-    const float xpub = xnext;
+    const unsigned xpub = xnext;
     const f32x4 pcur[2] = {pnext[0], pnext[1]};
     if (PREIN) load_p(t + 1 < Tn ? t + 1 : Tn - 1, pnext);
     else xnext = load_x(t + 2 < Tn ? t + 2 : Tn - 1);
@@ -379,7 +389,8 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
 // product with ONE fma per result (dh += partial * 2^-k): no cross-wave maximum, no extra barrier.
 // d_bz, d_bh, d_zeta, d_nu partial sums per workgroup.  mode bit 1 (FASTGRNN_FLAG_GRAD_LAST): ghs is [B,H], the
 // gradient of the last state alone.
-template <int GATE, bool PREACT, bool RAGGED>
+// BF: FASTGRNN_BF16_IO -- grad_hs and hs are bf16 in HBM (the saved pre-activation, h0, d_pre and d_h0 stay fp32).
+template <int GATE, bool PREACT, bool RAGGED, bool BF = false>
 __global__ __launch_bounds__(512) void bwd_scan_h256(
     int Tn, int B, int mode, unsigned hsT, unsigned hsB, const float* __restrict__ ghs, const float* __restrict__ hs,
     const float* __restrict__ aux0, const float* __restrict__ aux1, const float* __restrict__ h0,
@@ -452,6 +463,15 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   auto ldg = [](const float* base, unsigned off) __attribute__((always_inline)) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
   };
+  // four bf16 sequence elements as raw bits in .xy (fp32 byte offset halved); widened where they are consumed
+  auto ldgb = [](const float* base, unsigned off) __attribute__((always_inline)) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + (off >> 1));
+    return f32x4{bitsf(r.x), bitsf(r.y), 0.f, 0.f};
+  };
+  auto widen = [](const f32x4 r) __attribute__((always_inline)) {
+    const unsigned a = fbits(r[0]), c = fbits(r[1]);
+    return f32x4{bitsf(a << 16), bitsf(a & 0xFFFF0000u), bitsf(c << 16), bitsf(c & 0xFFFF0000u)};
+  };
   const unsigned dp_step = valid ? hsT * 4u : 0u;
   const unsigned dp_off = valid ? lane_v : (((unsigned)Tn * (unsigned)B + i) * H2 + n0) * 4u;
   auto stg = [](float* base, unsigned off, f32x4 v) __attribute__((always_inline)) {
@@ -460,20 +480,21 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
   struct EwOps { f32x4 g[2], a0[2], a1[2], h[2]; };
   auto load_ew = [&](int t, EwOps& e) __attribute__((always_inline)) {
     const size_t step = (size_t)t * hsT;                                     // uniform
-    const float* gt = g_last ? ghs : ghs + step;
+    const size_t sstep = BF ? step / 2 : step;                               // (in floats) of a bf16 sequence
+    const float* gt = g_last ? ghs : ghs + sstep;
     const float* p0 = aux0 + step;
     const float* p1 = PREACT ? aux0 : aux1 + step;
-    const float* ht = (t == 0) ? h0 : hs + (step - (size_t)hsT);            // .cu:478-481
+    const float* ht = (t == 0) ? h0 : hs + (sstep - (BF ? (size_t)hsT / 2 : (size_t)hsT));   // .cu:478-481
     const unsigned lane_g = g_last ? lane_c0 : lane_c, lane_h = (t == 0) ? lane_c0 : lane_c;
     const bool g_zero = (g_last && t != Tn - 1) || (RAGGED && !valid);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       // lanes beyond a ragged batch: the last utterance's rows with a ZERO gradient (dh starts at zero: gg, d_pre and
       // every sum they enter stay exactly zero for them)
-      e.g[mt] = g_zero ? z4 : ldg(gt, lane_g + 64u * mt);
+      e.g[mt] = g_zero ? z4 : (BF ? ldgb(gt, lane_g + 64u * mt) : ldg(gt, lane_g + 64u * mt));
       e.a0[mt] = ldg(p0, lane_c + 64u * mt);
       if (!PREACT) e.a1[mt] = ldg(p1, lane_c + 64u * mt);
-      e.h[mt] = ldg(ht, lane_h + 64u * mt);
+      e.h[mt] = (BF && t > 0) ? ldgb(ht, lane_h + 64u * mt) : ldg(ht, lane_h + 64u * mt);   // (h0 is fp32)
     }
   };
 
@@ -494,6 +515,10 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       if (PREACT) {
         bzq = *reinterpret_cast<const f32x4*>(&sbias[0][n0 + 16 * mt]);
         bhq = *reinterpret_cast<const f32x4*>(&sbias[1][n0 + 16 * mt]);
+      }
+      if (BF) {
+        e.g[mt] = widen(e.g[mt]);
+        if (t > 0) e.h[mt] = widen(e.h[mt]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -723,10 +748,10 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
     x = xtm;
   }
   // a wider input (F = 64 / 128): the batched frame GEMM  P = X . W^T  into the workspace, then the PREIN scan on P
-  const bool prein = d.F != F2;
+  const bool prein = d.F != F2, bf = d.dtype == FASTGRNN_BF16_IO;
   if (prein) {
     float* P = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + h256_flag_bytes(d));
-    rows_gemm((size_t)d.T * d.B, H2, d.F, false, x, (const float*)p.w, P, false, false, s);
+    rows_gemm((size_t)d.T * d.B, H2, d.F, false, x, (const float*)p.w, P, bf, false, s);   // (bf16 frames, fp32 P)
     x = P;
   }
   // strides of the sequences (elements): FASTGRNN_FLAG_BATCH_MAJOR lays hs / zs / cs and x out as [B,T,*]; the
@@ -744,18 +769,25 @@ void launch_fwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* x,
   const bool h16 = BOUNDED && !(d.flags & FASTGRNN_FLAG_FWD_BF16X3);
   auto pick = [&](auto aux_tag) __attribute__((always_inline)) {
     constexpr int A = decltype(aux_tag)::value;
-    auto with = [&](auto prein_tag) __attribute__((always_inline)) {
-      constexpr bool PI = decltype(prein_tag)::value;
+    auto with = [&](auto prein_tag, auto bf_tag) __attribute__((always_inline)) {
+      constexpr bool PI = decltype(prein_tag)::value, BFV = decltype(bf_tag)::value;
       if constexpr (BOUNDED) {
         if (h16) {                                   // fp16 launch, then the bf16 one for workgroups it turned down
-          if (ragged) { go(fwd_scan_h256<GATE, A, true, 1, PI>); go(fwd_scan_h256<GATE, A, true, 2, PI>); }
-          else        { go(fwd_scan_h256<GATE, A, false, 1, PI>); go(fwd_scan_h256<GATE, A, false, 2, PI>); }
+          if (ragged) { go(fwd_scan_h256<GATE, A, true, 1, PI, BFV>); go(fwd_scan_h256<GATE, A, true, 2, PI, BFV>); }
+          else        { go(fwd_scan_h256<GATE, A, false, 1, PI, BFV>); go(fwd_scan_h256<GATE, A, false, 2, PI, BFV>); }
           return;
         }
       }
-      if (ragged) go(fwd_scan_h256<GATE, A, true, 0, PI>); else go(fwd_scan_h256<GATE, A, false, 0, PI>);
+      if (ragged) go(fwd_scan_h256<GATE, A, true, 0, PI, BFV>); else go(fwd_scan_h256<GATE, A, false, 0, PI, BFV>);
     };
-    if (prein) with(std::true_type{}); else with(std::false_type{});
+    // bf16 sequences (h256_supported: gates sigmoid / relu / tanh, hs alone or the one-saved-tensor contract)
+    if constexpr (GATE <= FASTGRNN_NL_TANH && (A == 0 || A == 2)) {
+      if (bf) {
+        if (prein) with(std::true_type{}, std::true_type{}); else with(std::false_type{}, std::true_type{});
+        return;
+      }
+    }
+    if (prein) with(std::true_type{}, std::false_type{}); else with(std::false_type{}, std::false_type{});
   };
   if (aux == 3) pick(std::integral_constant<int, 3>{});
   else if (aux == 2) pick(std::integral_constant<int, 2>{});
@@ -779,24 +811,34 @@ void launch_bwd(const fastgrnn_desc& d, const fastgrnn_params& p, const void* gh
                        (const float*)p.u, (const float*)p.bias_gate, (const float*)p.bias_update, (const float*)p.zeta,
                        (const float*)p.nu, (float*)g.d_h0, dpre, part);
   };
-  if (preact) { if (ragged) go(bwd_scan_h256<GATE, true, true>); else go(bwd_scan_h256<GATE, true, false>); }
-  else        { if (ragged) go(bwd_scan_h256<GATE, false, true>); else go(bwd_scan_h256<GATE, false, false>); }
+  const bool bf = d.dtype == FASTGRNN_BF16_IO;       // (h256_supported: under SAVE_PREACT, gates sigmoid / relu / tanh)
+  bool launched = false;
+  if constexpr (GATE <= FASTGRNN_NL_TANH) {
+    if (bf) {
+      if (ragged) go(bwd_scan_h256<GATE, true, true, true>); else go(bwd_scan_h256<GATE, true, false, true>);
+      launched = true;
+    }
+  }
+  if (!launched) {
+    if (preact) { if (ragged) go(bwd_scan_h256<GATE, true, true>); else go(bwd_scan_h256<GATE, true, false>); }
+    else        { if (ragged) go(bwd_scan_h256<GATE, false, true>); else go(bwd_scan_h256<GATE, false, false>); }
+  }
   hipLaunchKernelGGL(reduce_h256_small, dim3((2 * H2 + 2 + 63) / 64), dim3(1024), 0, s, nwg, part, (const float*)p.zeta,
                      (const float*)p.nu, (float*)g.d_bias_gate, (float*)g.d_bias_update, (float*)g.d_zeta, (float*)g.d_nu);
   const size_t TB = (size_t)d.T * d.B;
   // dU = d_pre^T . H_prev (rows of t = 0 are h0, the rest hs[t-1]);  dW = d_pre^T . X   (.cu:539-540 over all steps)
   // (batch-major: row b*T + t of d_pre pairs with hs row b*T + t - 1, every T-th row with h0[b])
-  if (bm) tn_gemm_big_run_periodic(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.T, H2, tn, (float*)g.d_u, H2, s);
-  else tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, (const float*)hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s);
+  if (bm) tn_gemm_big_run_periodic(TB, H2, H2, dpre, H2, (const float*)h0, hs, (size_t)d.T, H2, tn, (float*)g.d_u, H2, s, bf);
+  else tn_gemm_big_run(TB, H2, H2, dpre, H2, (const float*)h0, hs, (size_t)d.B, H2, tn, (float*)g.d_u, H2, s, bf);
   const bool bft = (d.flags & FASTGRNN_FLAG_X_BFT) != 0;
   float* xtm = (float*)(base + L.xtm);
   if (bft) bft_transpose_f32(d.B, d.T, (const float*)x, xtm, true, s);
   const float* xr = bft ? xtm : (const float*)x;
-  tn_gemm_big_run(TB, H2, d.F, dpre, H2, xr, xr, (size_t)0, d.F, tn, (float*)g.d_w, d.F, s);
+  tn_gemm_big_run(TB, H2, d.F, dpre, H2, xr, xr, (size_t)0, d.F, tn, (float*)g.d_w, d.F, s, bf);
   // d_x = d_pre . W   (.cu:538; W is [H,F] = [K,N]); skipped when the caller does not want the input's gradient
   // (g.d_x == NULL: the first layer of a model, whose input is data)
   if (g.d_x) {
-    rows_gemm(TB, d.F, H2, true, dpre, (const float*)p.w, bft ? (void*)xtm : g.d_x, false, false, s);
+    rows_gemm(TB, d.F, H2, true, dpre, (const float*)p.w, bft ? (void*)xtm : g.d_x, false, bf, s);   // (bf16 d_x)
     if (bft) bft_transpose_f32(d.B, d.T, xtm, (float*)g.d_x, false, s);
   }
 }
@@ -808,9 +850,17 @@ bool h256_shape(const fastgrnn_desc& d) {
   return d.w_rank == 0 && d.u_rank == 0 && d.H == H2 && (d.F == F2 || d.F == 64 || d.F == 128) && d.B < (1 << 21);
 }
 
-// fp32 sequences, time- or batch-major, every gate, both saved-tensor contracts, full or last-state outputs / gradients
+// fp32 sequences, time- or batch-major, every gate, both saved-tensor contracts, full or last-state outputs / gradients;
+// bf16 sequences with the limits below
 bool h256_supported(const fastgrnn_desc& d, int direction) {
-  if (!h256_shape(d) || d.dtype != FASTGRNN_F32) return false;
+  if (!h256_shape(d) || (d.dtype != FASTGRNN_F32 && d.dtype != FASTGRNN_BF16_IO)) return false;
+  if (d.dtype == FASTGRNN_BF16_IO) {
+    // bf16 sequences (x, hs, grad_hs, d_x): gates sigmoid / relu / tanh; the forward with hs alone or under
+    // FASTGRNN_FLAG_SAVE_PREACT, the backward under it; no [B,F,T] frames, no last-state forward
+    if (d.gate_nl > FASTGRNN_NL_TANH || (d.flags & (FASTGRNN_FLAG_X_BFT | FASTGRNN_FLAG_HS_LAST))) return false;
+    if (direction == 1 && !(d.flags & FASTGRNN_FLAG_SAVE_PREACT)) return false;
+    if (direction == 1 && (d.flags & FASTGRNN_FLAG_BATCH_MAJOR)) return false;   // (no bf16 variant of the periodic dU GEMM)
+  }
   if (d.F != F2 && (d.flags & FASTGRNN_FLAG_X_BFT)) return false;      // (the loader's [B,F,T] batches: 32 features)
   // batch-major sequences: two-stride rows in both scans; the backward's d_pre rows then follow [B,T], which a
   // time-major workspace copy of [B,F,T] frames would not match

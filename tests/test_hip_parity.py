@@ -579,14 +579,15 @@ def test_batch_major_layout_equals_time_major(B, preact):
                                      flags=BATCH_MAJOR | 1)
 
 
+@pytest.mark.parametrize("F,H", [(32, 128), (32, 256), (64, 256)], ids=["F32H128", "F32H256", "F64H256"])
 @pytest.mark.parametrize("B,batch_major", [(64, False), (37, False), (48, True)])
-def test_bf16_sequences_fp32_master_grads(B, batch_major):
+def test_bf16_sequences_fp32_master_grads(B, batch_major, F, H):
     """BASELINE config "fwd+bwd training step, bf16 with fp32 master grads" (parity unpinned by the
     reference, which has no such type): x, hs, grad_hs, d_x are bf16 in HBM; state, parameters, the
     saved pre-activation and every parameter gradient are fp32.  Checked against the fp64 oracle run
     on the SAME rounded tensors: hs and d_x to bf16 rounding (2^-8 relative), the fp32 outputs to the
     fp32 tolerances of the other tests."""
-    T, F, H = 31, 32, 128
+    T = 31                                # (H = 256: the first layer of the default stack, round 3)
     SAVE_PREACT, BATCH_MAJOR = 4, 16
     rng = np.random.default_rng(77 + B)
     p = O.make_params(F, H, dtype=np.float32, seed=23, randomize_scalars=True)
@@ -599,14 +600,17 @@ def test_bf16_sequences_fp32_master_grads(B, batch_major):
     lay = (lambda t: t.transpose(0, 1).contiguous()) if batch_major else (lambda t: t)
     unlay = (lambda t: t.transpose(0, 1)) if batch_major else (lambda t: t)
     xt, Gt, ht = lay(x_bf).to(DEV), lay(G_bf).to(DEV), _t(h0)
-    assert fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=1, flags=flags) == 2
+    bwd_fast = not (H == 256 and batch_major)   # (the H = 256 backward takes bf16 sequences time-major only; the module transposes)
+    assert fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=0, flags=flags) == 2
+    assert (fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=1, flags=flags) == 2) == bwd_fast
     hs, pre = fastgrnn_cuda.forward_unroll(xt, P["w"], P["u"], P["bias_gate"], P["bias_update"], P["zeta"], P["nu"], ht,
                                            0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags)
     assert hs.dtype == torch.bfloat16 and pre.dtype == torch.float32
-    outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
-                                         P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags,
-                                         bias_gate=P["bias_gate"], bias_update=P["bias_update"])
-    assert outs[0].dtype == torch.bfloat16 and outs[6].dtype == torch.float32
+    if bwd_fast:
+        outs = fastgrnn_cuda.backward_unroll(Gt, xt, hs, P["zeta"], P["nu"], P["w"], P["u"], pre, pre, ht,
+                                             P["w1"], P["w2"], P["u1"], P["u2"], 0, flags=flags,
+                                             bias_gate=P["bias_gate"], bias_update=P["bias_update"])
+        assert outs[0].dtype == torch.bfloat16 and outs[6].dtype == torch.float32
     # ---- forward against the oracle on the rounded x: fp32 state inside, bf16 only when stored
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     x64 = x_bf.to(torch.float64).numpy(); G64 = G_bf.to(torch.float64).numpy(); h64 = h0.astype(np.float64)
@@ -615,6 +619,8 @@ def test_bf16_sequences_fp32_master_grads(B, batch_major):
     assert (np.abs(hs_k - hs_o) / np.maximum(1.0, np.abs(hs_o))).max() <= 2.0 ** -8 + 1e-5   # one bf16 rounding (RNE: 2^-9 relative)
     hprev = np.concatenate([h64[None], hs_o[:-1]], 0)
     assert np.abs(unlay(pre).cpu().numpy() - (x64 @ p64["w"].T + hprev @ p64["u"].T)).max() <= 1e-5
+    if not bwd_fast:
+        return
     # ---- backward: the kernel sees the ROUNDED hs as h_prev (what autograd with bf16 activations does):
     #      oracle on the same tensors, gates from the exact pre-activation
     hs_r = hs_k.copy()
@@ -633,14 +639,20 @@ def test_bf16_sequences_fp32_master_grads(B, batch_major):
                                      0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags & ~SAVE_PREACT)
 
 
-def test_module_bf16_sequences_autograd():
+@pytest.mark.parametrize("F,H,batch_first", [(32, 128, False), (32, 256, False), (64, 256, False), (32, 256, True)])
+def test_module_bf16_sequences_autograd(F, H, batch_first):
     """FastGRNNCUDA fed bf16 frames: bf16 hidden states out, bf16 d_input and fp32 parameter gradients
-    back; agrees with the same module run in fp32 on the rounded frames to bf16 rounding."""
-    T, B, F, H = 25, 40, 32, 128
+    back; agrees with the same module run in fp32 on the rounded frames to bf16 rounding.  (H = 256, round 3: the
+    dense H = 256 scans and their GEMMs take bf16 sequences; batch_first there runs on transposed copies.)"""
+    T, B = 25, 40
     torch.manual_seed(5)
-    m = FastGRNNCUDA(F, H, device=DEV)
+    m = FastGRNNCUDA(F, H, batch_first=batch_first, device=DEV)
     x = torch.randn(T, B, F).to(torch.bfloat16)
     G = torch.randn(T, B, H).to(torch.bfloat16)
+    if batch_first:
+        x, G = x.transpose(0, 1).contiguous(), G.transpose(0, 1).contiguous()
+    else:
+        assert fastgrnn_cuda.kernel_path(T, B, F, H, dtype=torch.bfloat16, direction=1, flags=4) == 2
     xb = x.to(DEV).requires_grad_(True)
     hb = m(xb)
     assert hb.dtype == torch.bfloat16
