@@ -1021,7 +1021,11 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   };
   if (d.update_nl == FASTGRNN_NL_QUANT_TANH) {       // fp32, SAVE_PREACT, F = 32 (split_supported)
     if (ragged) go8(bwd_scan_split_w8<GATE, true, true, false, false, true>); else go8(bwd_scan_split_w8<GATE, true, false, false, false, true>);
-  } else if (wide) {                                 // fp32 sequences (split_supported); both saved-tensor contracts
+  } else if (wide && d.dtype == FASTGRNN_BF16_IO) {  // SAVE_PREACT, gates sigmoid / relu / tanh (split_supported)
+    if constexpr (GATE <= FASTGRNN_NL_TANH) {
+      if (ragged) go8(bwd_scan_split_w8<GATE, true, true, true, true>); else go8(bwd_scan_split_w8<GATE, true, false, true, true>);
+    }
+  } else if (wide) {                                 // fp32 sequences; both saved-tensor contracts
     if (preact) { if (ragged) go8(bwd_scan_split_w8<GATE, true, true, false, true>); else go8(bwd_scan_split_w8<GATE, true, false, false, true>); }
     else        { if (ragged) go8(bwd_scan_split_w8<GATE, false, true, false, true>); else go8(bwd_scan_split_w8<GATE, false, false, false, true>); }
   } else if (d.dtype == FASTGRNN_BF16_IO) {
@@ -1038,10 +1042,11 @@ void launch_bwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
   if (wide) {
     const size_t TB = (size_t)d.T * d.B;
     // dW[H,F] = d_pre^T . X   (.cu:539 summed over the steps)
-    tn_gemm_big_run(TB, 128, d.F, dpre, 128, (const float*)x, (const float*)x, (size_t)0, d.F,
-                    reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.tn), (float*)g.d_w, d.F, s);
+    const bool bfw = d.dtype == FASTGRNN_BF16_IO;    // (x and d_x are bf16 then; d_pre is fp32 always)
+    tn_gemm_big_run(TB, 128, d.F, dpre, 128, (const float*)x, x, (size_t)0, d.F,
+                    reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + L.tn), (float*)g.d_w, d.F, s, bfw);
     // d_x[T*B,F] = d_pre . W   (.cu:538 for every step at once; W is [H,F] = [K,N])
-    if (g.d_x) rows_gemm(TB, d.F, 128, true, dpre, (const float*)p.w, g.d_x, false, false, s);   // (NULL: not wanted)
+    if (g.d_x) rows_gemm(TB, d.F, 128, true, dpre, (const float*)p.w, g.d_x, false, bfw, s);   // (NULL: not wanted)
   }
 }
 
@@ -1085,7 +1090,19 @@ void launch_fwd_gate(const fastgrnn_desc& d, const fastgrnn_params& p, const voi
         return;
       }
     }
-    if (prein) {                                     // fp32 sequences only (split_supported)
+    if constexpr (GATE <= FASTGRNN_NL_TANH && (A == 0 || A == 2)) {
+      if (prein && bf) {                             // wide layer, bf16 hs (P is fp32 whatever the frames are)
+        if constexpr (BOUNDED) {
+          if (h16) {
+            if (ragged) go8(fwd_scan_split_w8<GATE, A, true, true, true, true>); else go8(fwd_scan_split_w8<GATE, A, false, true, true, true>);
+            return;
+          }
+        }
+        if (ragged) go8(fwd_scan_split_w8<GATE, A, true, true, false, true>); else go8(fwd_scan_split_w8<GATE, A, false, true, false, true>);
+        return;
+      }
+    }
+    if (prein) {                                     // fp32 sequences
       if constexpr (BOUNDED) {
         if (h16) {
           if (ragged) go8(fwd_scan_split_w8<GATE, A, true, false, true, true>); else go8(fwd_scan_split_w8<GATE, A, false, false, true, true>);
@@ -1153,7 +1170,10 @@ bool split_supported(const fastgrnn_desc& d, int direction) {
   // dense H = 128 with a wider input (F = 64 / 128 / 256; the reference's second layer): recurrence-only scans +
   // batched GEMMs.  fp32 sequences, time- or batch-major, every gate, full or last-state outputs / gradients.
   if (dense_wide_shape(d)) {
-    if (d.dtype != FASTGRNN_F32 || (d.flags & FASTGRNN_FLAG_X_BFT)) return false;
+    if (d.flags & FASTGRNN_FLAG_X_BFT) return false;
+    if (d.dtype == FASTGRNN_BF16_IO)                 // bf16 sequences (round 3): the reference's three gates, no last-state
+      return d.gate_nl <= FASTGRNN_NL_TANH &&        // flags, the backward under the one-saved-tensor contract
+             !(d.flags & (FASTGRNN_FLAG_HS_LAST | FASTGRNN_FLAG_GRAD_LAST)) && (direction == 0 || preact);
     if (direction == 0 && preact && (d.flags & FASTGRNN_FLAG_HS_LAST)) return false;
     return d.gate_nl <= FASTGRNN_NL_TANH || direction == 0 || preact;
   }
@@ -1224,7 +1244,7 @@ int split_forward(const fastgrnn_desc& d, const fastgrnn_params& p, const void* 
     // the workspace when the caller wants neither
     pws = zs == nullptr ? ws : ((d.flags & FASTGRNN_FLAG_SAVE_PREACT) ? zs : cs);
     if (!pws) return FASTGRNN_ERR_WORKSPACE;
-    const int st = rows_gemm((size_t)d.T * d.B, 128, d.F, false, x, (const float*)p.w, pws, false, false, s);
+    const int st = rows_gemm((size_t)d.T * d.B, 128, d.F, false, x, (const float*)p.w, pws, d.dtype == FASTGRNN_BF16_IO, false, s);
     if (st != FASTGRNN_OK) return st;
   }
   switch (d.gate_nl) {

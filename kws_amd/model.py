@@ -93,12 +93,13 @@ class RNNClassifierModel(nn.Module):
         top = self.num_layers - 1
         for l, rnn in enumerate(self.rnn_list):
             out = rnn(rnn_in, hiddenState=self.hidden_states[l], last_state=(l == top))
+            # (bf16 sequences: the state a layer carries over is fp32, like the one it starts from)
             if l == top:
-                self.hidden_states[l] = out.detach()
+                self.hidden_states[l] = out.detach().float()
             else:
-                self.hidden_states[l] = (out.detach()[:, -1, :] if self.batch_first else out.detach()[-1, :, :])
+                self.hidden_states[l] = (out.detach()[:, -1, :] if self.batch_first else out.detach()[-1, :, :]).float()
             rnn_in = out
-        return rnn_in
+        return rnn_in.float()                              # (the head is fp32; a no-op for fp32 sequences)
 
     def forward(self, input):
         """[T,B,F] (or [B,T,F] with ``batch_first``) -> keyword scores [B,C] (model.py:185-231)."""

@@ -579,7 +579,8 @@ def test_batch_major_layout_equals_time_major(B, preact):
                                      flags=BATCH_MAJOR | 1)
 
 
-@pytest.mark.parametrize("F,H", [(32, 128), (32, 256), (64, 256)], ids=["F32H128", "F32H256", "F64H256"])
+@pytest.mark.parametrize("F,H", [(32, 128), (32, 256), (64, 256), (256, 128), (64, 128)],
+                         ids=["F32H128", "F32H256", "F64H256", "F256H128", "F64H128"])
 @pytest.mark.parametrize("B,batch_major", [(64, False), (37, False), (48, True)])
 def test_bf16_sequences_fp32_master_grads(B, batch_major, F, H):
     """BASELINE config "fwd+bwd training step, bf16 with fp32 master grads" (parity unpinned by the
@@ -639,7 +640,8 @@ def test_bf16_sequences_fp32_master_grads(B, batch_major, F, H):
                                      0, P["w1"], P["w2"], P["u1"], P["u2"], flags=flags & ~SAVE_PREACT)
 
 
-@pytest.mark.parametrize("F,H,batch_first", [(32, 128, False), (32, 256, False), (64, 256, False), (32, 256, True)])
+@pytest.mark.parametrize("F,H,batch_first", [(32, 128, False), (32, 256, False), (64, 256, False), (32, 256, True),
+                                             (256, 128, False), (256, 128, True)])
 def test_module_bf16_sequences_autograd(F, H, batch_first):
     """FastGRNNCUDA fed bf16 frames: bf16 hidden states out, bf16 d_input and fp32 parameter gradients
     back; agrees with the same module run in fp32 on the rounded frames to bf16 rounding.  (H = 256, round 3: the

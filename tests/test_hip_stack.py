@@ -298,6 +298,37 @@ def test_two_layer_model_full_batch_vs_fp64_oracle_and_inference_path():
     assert (np.abs(scores.cpu().numpy() - scores_o) / np.maximum(1.0, np.abs(scores_o))).max() <= 1e-5
 
 
+def test_two_layer_model_with_bf16_sequences(stack_golden):
+    """BASELINE config 3 ("bf16 with fp32 master grads") for the default stack: bf16 frames in, bf16 hidden-state
+    sequences between the layers, fp32 state / parameters / parameter gradients; both layers on the matrix-pipe
+    kernels.  Against the same model run in fp32 on the rounded frames: loss to 2e-3, gradients to 2 % of their
+    largest element (each layer's hs is rounded once to bf16: 2^-9 relative per element)."""
+    g = stack_golden
+    T, B, F = g["x"].shape
+    for F_l, H_l in ((F, g["hidden"][0]), (g["hidden"][0], g["hidden"][1])):
+        for direction in (0, 1):
+            assert fastgrnn_cuda.kernel_path(T, B, F_l, H_l, dtype=torch.bfloat16, direction=direction,
+                                             flags=_lib.FLAG_SAVE_PREACT) == 2
+    m = _build_model(g)
+    y = _t(g["labels"])
+    xb = _t(g["x"].astype(np.float32)).to(torch.bfloat16)
+    res = []
+    for x in (xb, xb.float()):
+        for p_ in m.parameters():
+            p_.grad = None
+        m.init_hidden()
+        xin = x.clone().requires_grad_(True)
+        loss = m.loss(xin, y)
+        loss.backward()
+        assert xin.grad.dtype == x.dtype
+        res.append((float(loss), xin.grad.float().clone(), {n: p_.grad.clone() for n, p_ in m.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-3
+    rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    assert rel(res[0][1], res[1][1]) <= 2e-2
+    for n in res[0][2]:
+        assert res[0][2][n].dtype == torch.float32 and rel(res[0][2][n], res[1][2][n]) <= 2e-2, (n, rel(res[0][2][n], res[1][2][n]))
+
+
 @pytest.mark.parametrize("want_dx", [False, True])
 def test_two_layer_model_reads_the_loaders_batch_in_place(stack_golden, want_dx):
     """The trainer feeds `audio.permute(2, 0, 1)` of the loader's [B,F,T] batch (trainClassifier.py:204,299); the
