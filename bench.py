@@ -167,6 +167,19 @@ def extra_configs(dev, B):
                                 {"layer1": [fastgrnn_cuda.kernel_path(T, B, F, 256, direction=d_, flags=4) for d_ in (0, 1)],
                                  "layer2": [fastgrnn_cuda.kernel_path(T, B, 256, 128, direction=d_, flags=4 | (256 if d_ else 0)) for d_ in (0, 1)]})
     res["stack_2layer"]["wx_gemm"] = wx
+    # the same model on bf16 sequences (config 3's contract on the stack: bf16 frames and hidden-state sequences, fp32
+    # state, parameters and parameter gradients)
+    xb16 = x.to(torch.bfloat16)
+
+    def step_stack_bf16():
+        for p_ in pst:
+            p_.grad = None
+        ms.init_hidden()
+        ms.loss(xb16, y).backward()
+    res["stack_2layer_bf16"] = entry(_time_steps(step_stack_bf16, 5, 10, 20), B * (2 * T * F + 8), B * fl_stack,
+                                     "the same model, bf16 x / hs between the layers / grad_hs, fp32 state and master gradients",
+                                     {"layer1": [fastgrnn_cuda.kernel_path(T, B, F, 256, dtype=torch.bfloat16, direction=d_, flags=4) for d_ in (0, 1)],
+                                      "layer2": [fastgrnn_cuda.kernel_path(T, B, 256, 128, dtype=torch.bfloat16, direction=d_, flags=4) for d_ in (0, 1)]})
     return res
 
 

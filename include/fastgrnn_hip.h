@@ -160,17 +160,22 @@ const char *fastgrnn_hip_status_string(int status);
  *   dense  H=128, F=32            every gate; update tanh or quantTanh (quantTanh: fp32, SAVE_PREACT backward);
  *                                 all layout flags.  Backward with the reference's (z_s, h_prime_s) tensors for the
  *                                 sigmoid / relu / tanh gates, otherwise under FASTGRNN_FLAG_SAVE_PREACT.
- *   dense  H=128, F=64/128/256    (the reference's second layer) fp32; time- or batch-major; last-state flags.
- *   dense  H=256, F=32            (the reference's first layer) fp32; time- or batch-major (two-stride rows in
+ *   dense  H=128, F=64/128/256    (the reference's second layer) time- or batch-major; last-state flags (fp32).
+ *                                 bf16 sequences: gates sigmoid / relu / tanh, no last-state flags, backward under
+ *                                 FASTGRNN_FLAG_SAVE_PREACT.
+ *   dense  H=256, F=32            (the reference's first layer) time- or batch-major (two-stride rows in
  *                                 both scans, the dU GEMM pairs row b*T+t with hs row b*T+t-1 and every T-th row
  *                                 with h0); x in the sequences' layout or the
  *                                 loader's [B,F,T] (FASTGRNN_FLAG_X_BFT: transposed into the workspace by both
  *                                 calls, 25 us at B = 4096; d_x comes back as [B,F,T]; the backward with BOTH
  *                                 FASTGRNN_FLAG_X_BFT and FASTGRNN_FLAG_BATCH_MAJOR is not on path 2); last-state
  *                                 flags; gates sigmoid / relu / tanh with the reference's (z_s, h_prime_s)
- *                                 tensors, every gate under FASTGRNN_FLAG_SAVE_PREACT.
+ *                                 tensors, every gate under FASTGRNN_FLAG_SAVE_PREACT.  bf16 sequences: gates
+ *                                 sigmoid / relu / tanh; forward with hs alone or under FASTGRNN_FLAG_SAVE_PREACT
+ *                                 (time- or batch-major), backward under it (time-major); no [B,F,T] frames, no
+ *                                 FASTGRNN_FLAG_HS_LAST.
  *   dense  H=256, F=64/128        (F = 64: the reference's DEFAULT first layer, feature_type='delta' = 32 MFCCs + 32
- *                                 deltas, trainingConfig.py:36, mfccProcessor.py:27-28) fp32, time- or batch-major; as F=32
+ *                                 deltas, trainingConfig.py:36, mfccProcessor.py:27-28) time- or batch-major; as F=32
  *                                 but without FASTGRNN_FLAG_X_BFT: the frame product X.W^T is one batched GEMM into
  *                                 the workspace (T*B*256*4 bytes more of it) in front of the scan.
  *   low-rank H=256, F=32, both W and U factorised with 1 <= rank <= 16 (the two ranks may differ; ranks are
