@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     const float* __restrict__ zeta, const float* __restrict__ nu,
     float* __restrict__ d_h0, float* __restrict__ dpre_ws, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[U2L + 3 * PLH2];
-  __shared__ __attribute__((aligned(16))) float sinv[16][8];        // 2^-k of slice (utterance, producer wave)
+  __shared__ __attribute__((aligned(16))) float smax[16][8];        // largest |d_pre_t| of (utterance, producer wave)
   __shared__ __attribute__((aligned(16))) float sbias[2][H2];
   __shared__ float red[16];
 
@@ -549,20 +549,31 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(o + 64 * mt) = dpv[mt];
     }
-    // ---- the slice's power of two: largest |d_pre| of utterance i over this wave's 32 units into [2^11, 2^12) ---
+    // ---- the utterance's power of two: largest |d_pre_t| over all 256 units into [2^11, 2^12).  Each wave leaves the
+    //      maximum over ITS 32 units in LDS before the barrier the step needs anyway, and reads all eight behind it: one
+    //      exact scale per utterance and step, so the chain's eight K-steps accumulate in the matrix pipe (C-in) and are
+    //      un-scaled ONCE -- round 3's first form scaled per (utterance, 32-unit slice) and paid an add and an fma per
+    //      result and K-step for it (128 fp32 vector instructions per wave and step: vector time adds to matrix time,
+    //      DESIGN.md 4.0).  Values below 2^-26 of the utterance's largest lose low bits in the planes: an absolute error
+    //      below 2^-36 of that largest element, against the 2^-24 an fp32 sum over them carries.
     amax = fmaxf(amax, __shfl_xor(amax, 16));
     amax = fmaxf(amax, __shfl_xor(amax, 32));
-    int ex = 12;                                     // all-zero slice (or inf / NaN, which propagate anyway): scale 1
-    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);       // amax = f * 2^ex, f in [0.5, 1)
-    ex = ex < -112 ? -112 : ex;                      // (2^(12-ex) must stay a normal float)
-    const float dscale = ldexpf(1.0f, 12 - ex);
+    if (g == 0) smax[i][wv] = amax;
     SPLIT_STAMP(1)
     lds_barrier();                                   // every wave has finished reading the planes of step t+1
     SPLIT_STAMP(2)
-    // (the slice's own factor only: the factor of U^T belongs to the CONSUMER's rows and is applied in req().  Round 2
-    // shipped this line with the producer's u_unscale folded in -- right only while every wave's block of U^T has its
-    // maximum in the same binade, which random 0.1-scale matrices happen to satisfy and a product U2.U1 does not)
-    if (g == 0) sinv[i][wv] = ldexpf(1.0f, ex - 12);
+    {
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(&smax[i][0]), m1 = *reinterpret_cast<const f32x4*>(&smax[i][4]);
+      amax = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
+    }
+    int ex = 12;                                     // all-zero rows (or inf / NaN, which propagate anyway): scale 1
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);       // amax = f * 2^ex, f in [0.5, 1)
+    ex = ex < -112 ? -112 : ex;                      // (2^(12-ex) must stay a normal float)
+    const float dscale = ldexpf(1.0f, 12 - ex);
+    // (the factor of U^T belongs to the CONSUMER's rows -- this wave's own -- and is applied with the un-scaling below.
+    // Round 2 shipped the producer's u_unscale folded into the slice's factor: right only while every wave's block of
+    // U^T has its maximum in the same binade, which random 0.1-scale matrices happen to satisfy and a product U2.U1 does not)
+    const float unscale = ldexpf(1.0f, ex - 12) * u_unscale;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       uint2 p0q, p1q, p2q;
@@ -579,14 +590,13 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     // requests for EW(t-1): behind the reads of dh above (they may land in registers the last chain's fragments used)
     if (t > 0) load_ew(t - 1, e);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- chain(t): d_h = z*g + U^T d_pre_t (.cu:537): per K-step three fp16 MFMAs per row tile into a fresh
-    //      accumulator, un-scaled into dh by one fma per result -----------------------------------------------------
-    // Software pipeline over the K-steps, two operand sets: while the three MFMAs per tile of K-step k execute, the
-    // partial products of K-step k-1 are folded into dh (that read also proves K-step k-1 has retired) and the
-    // fragments of K-step k+1 are requested into the set K-step k-1 used.  Taking one K-step at a time and waiting
-    // for its MFMAs before the next request cost 350 cycles per K-step (tools/diag_h256.hip), most of it exposed LDS
-    // latency and pipe drain -- and the SIMD's second wave queues behind all of it.
-    struct KOps { Frag2h dB; u32x4 d2, Ul[2]; float inv; };
+    // ---- chain(t): d_h = z*g + U^T d_pre_t (.cu:537): per K-step five fp16 MFMAs per row tile, accumulated over the
+    //      eight K-steps in the matrix pipe and un-scaled into dh once ------------------------------------------------
+    // Software pipeline over the K-steps, two operand sets and two accumulator sets (even / odd K-steps): while the
+    // MFMAs of K-step k execute, a read of K-step k-1's accumulators proves that one has retired and the fragments of
+    // K-step k+1 are requested into the operand set it used.  (One accumulator set would make that read wait for
+    // K-step k as well; taking one K-step at a time cost 350 cycles per K-step, tools/diag_h256.hip.)
+    struct KOps { Frag2h dB; u32x4 d2, Ul[2]; };
     auto req = [&](int k, KOps& o) __attribute__((always_inline)) {
       const unsigned off = (unsigned)(i * ROWH2 + 64 * k + 16 * g);
       o.dB.hi = *reinterpret_cast<const u32x4*>(dpl + off);
@@ -594,31 +604,31 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       o.d2 = *reinterpret_cast<const u32x4*>(dpl + 2 * PLH2 + off);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) o.Ul[mt] = ulo[((wv * 2 + mt) * KS2 + k) * 64 + l];
-      o.inv = sinv[i][k] * u_unscale;
     };
     // Five terms per K-step and row tile (round 3): U^T as two fp16 planes (22 bits: a fixed relative perturbation of
     // the weights of 2^-23, the size of their own fp32 rounding), d_pre as THREE (exact), the one dropped term
     // (U^T's low plane against d_pre's third) below 2^-33.  The four small terms go into an accumulator of their own
     // (inside an MFMA the addends are chopped at the largest one: mfma6_hl).  With three terms -- two
     // planes of d_pre, lo.lo dropped -- d_zeta / d_nu sat at 4-5.5e-5 of the result at B = 4096 and 4.5e-4 on 8x weights.
+    // pr[mt]: big terms, pr[2 + mt]: small terms of one accumulator set
     auto issue = [&](int k, const KOps& o, f32x4* pr) __attribute__((always_inline)) {
+      const bool first = k < 2;                        // (compile-time: the set's first K-step starts from the constant 0)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        f32x4 a = mfma_f16(o.Ul[mt], o.dB.lo, z4);                   // smallest first
+        f32x4 a = mfma_f16(o.Ul[mt], o.dB.lo, first ? z4 : pr[2 + mt]);   // smallest first
         a = mfma_f16(UTh[mt][k], o.d2, a);
         a = mfma_f16(o.Ul[mt], o.dB.hi, a);
         pr[2 + mt] = mfma_f16(UTh[mt][k], o.dB.lo, a);
-        pr[mt] = mfma_f16(UTh[mt][k], o.dB.hi, z4);
+        pr[mt] = mfma_f16(UTh[mt][k], o.dB.hi, first ? z4 : pr[mt]);
       }
     };
-    auto fold = [&](const KOps& o, const f32x4* pr) __attribute__((always_inline)) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh[mt][r] = fmaf(pr[mt][r] + pr[2 + mt][r], o.inv, dh[mt][r]);
-      // (pinned: without a use here the optimiser sinks the fmas below later requests, and the completion read with
-      // them; the operand set stays allocated up to here -- the compiler considers it dead once its MFMAs have ISSUED)
-      asm volatile("" : "+v"(dh[0]), "+v"(dh[1]) : "v"(o.dB.hi), "v"(o.dB.lo), "v"(o.d2), "v"(o.Ul[0]), "v"(o.Ul[1]));
+    auto retire = [&](const KOps& o, const f32x4* pr) __attribute__((always_inline)) {
+      // one element of every accumulator the K-step wrote (the scheduler orders the two tiles' chains freely), combined
+      // with integer instructions (they ride between MFMAs for free, fp32 additions do not: DESIGN.md 4.0); the
+      // operand set stays allocated up to here -- the compiler considers it dead once its MFMAs have ISSUED
+      const unsigned bits = (fbits(pr[0][0]) | fbits(pr[1][0])) | (fbits(pr[2][0]) | fbits(pr[3][0]));
+      completion_read(bitsf(bits));
+      asm volatile("" :: "v"(o.dB.hi), "v"(o.dB.lo), "v"(o.d2), "v"(o.Ul[0]), "v"(o.Ul[1]));
     };
     KOps o0, o1;
     f32x4 p0[4], p1[4];
@@ -630,14 +640,19 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       if constexpr ((k & 1) == 0) issue(k, o0, p0); else issue(k, o1, p1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (k >= 1) {
-        // K-step k-1: fold (completion read), then its operand set is free for K-step k+1
-        if constexpr ((k & 1) == 0) { fold(o1, p1); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o1); }
-        else                        { fold(o0, p0); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o0); }
+        // K-step k-1 has retired: its operand set is free for K-step k+1
+        if constexpr ((k & 1) == 0) { retire(o1, p1); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o1); }
+        else                        { retire(o0, p0); __builtin_amdgcn_sched_barrier(0); if constexpr (k + 1 < KS2) req(k + 1, o0); }
         __builtin_amdgcn_sched_barrier(0);
       }
     });
-    fold(o1, p1);                                    // K-step 7
+    retire(o1, p1);                                  // K-step 7
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dh[mt][r] = fmaf((p0[mt][r] + p1[mt][r]) + (p0[2 + mt][r] + p1[2 + mt][r]), unscale, dh[mt][r]);
   };
 
   EwOps ea;
