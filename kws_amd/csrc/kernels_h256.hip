@@ -11,7 +11,7 @@
 //       re-reads only its own fragments, 16 ds_read_b128 per step, so the LDS acts as a second register file); six
 //       MFMA terms per K-step as everywhere else;
 //   backward:  U^T as two fp16 planes, hi in registers (64 per lane), lo in LDS; d_pre as two fp16 planes scaled by
-//       an exact power of two per (utterance, 32-unit slice) -- see bwd_scan_h256.
+//       an exact power of two per utterance and step -- see bwd_scan_h256.
 // Wave w owns hidden units 32w..32w+31 (two 16-row tiles, eight K-steps).  W (32 wide) stays fused in the forward as
 // in the H = 128 kernel.  The backward keeps the recurrence only and writes d_pre[T,B,H]: dU, dW and d_x are batched
 // GEMMs afterwards (kernels_gemm.hip; .cu:538-540 does them per step) -- neither U^T's planes nor the 256 KB of dU
@@ -382,11 +382,12 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
 // hi.hi) like the forward's state product: U^T's hi plane in registers (64 per lane), its lo plane in LDS in
 // fragment order (128 KB, each wave re-reading only its own fragments).  U^T is bounded and pre-scaled by one exact
 // power of two per wave.  d_pre is NOT bounded -- the reason kernels_split.hip keeps bf16 planes for gradients: a
-// small-magnitude gradient falls into fp16's subnormal range -- so every (utterance, producer wave) slice of 32
-// values is scaled by its own exact power of two that puts the slice's largest magnitude in [2^11, 2^12) before
-// the split: planes then resolve 2^-22 of the slice's largest element, which is what a dot product with that slice
-// needs.  A producer wave's 32 units are exactly one K-step of the chain, so the consumer un-scales each K-step's
-// product with ONE fma per result (dh += partial * 2^-k): no cross-wave maximum, no extra barrier.
+// small-magnitude gradient falls into fp16's subnormal range -- so every utterance's row of d_pre_t is scaled by its
+// own exact power of two that puts the row's largest magnitude in [2^11, 2^12) before the split into THREE fp16
+// planes (exact for everything within 2^-26 of that largest element).  The maximum over the row's 256 units crosses
+// the waves through LDS on the barrier the step has anyway; with ONE scale per utterance the chain's eight K-steps
+// accumulate in the matrix pipe and are un-scaled once per result (the first form scaled per 32-unit producer slice
+// to avoid the cross-wave maximum, and paid an add and an fma per result and K-step for it).
 // d_bz, d_bh, d_zeta, d_nu partial sums per workgroup.  mode bit 1 (FASTGRNN_FLAG_GRAD_LAST): ghs is [B,H], the
 // gradient of the last state alone.
 // BF: FASTGRNN_BF16_IO -- grad_hs and hs are bf16 in HBM (the saved pre-activation, h0, d_pre and d_h0 stay fp32).
