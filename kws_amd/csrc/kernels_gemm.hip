@@ -216,7 +216,9 @@ __device__ __forceinline__ int tnb_mblk(int bid, int nblk) { return (bid >> 3) %
 // sequences: shiftB = T; the first step of every utterance reads h0, the others the row before their own).
 // BF_B: B1 holds bf16 (FASTGRNN_BF16_IO sequences: x, hs), B0 (h0) stays fp32.  A bf16 value IS its own first plane
 // (the other two are zero): its rows are published from the raw 8 bytes with no vector arithmetic.
-template <int NT, bool PERIODIC = false, bool BF_B = false>
+// PURE (with BF_B): EVERY row of B is bf16 (no h0 rows: shiftB = 0) -- planes 1 and 2 of B are zero, are neither
+// published nor read, and a product is three of mfma6's six terms, in its order (same bits as the six).
+template <int NT, bool PERIODIC = false, bool BF_B = false, bool PURE = false>
 __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, int nblk, int nchunk, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B0, const float* __restrict__ B1,
                                                    size_t shiftB, int ldb, float* __restrict__ part) {
@@ -227,9 +229,10 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
   constexpr int NBATCH = MA == 4 ? (NH < 2 ? NH : 2) : (NH < 4 ? NH : 4);
   constexpr int ROWA = MB * 2 + 32, ROWB = N * 2 + 32;
   constexpr int VA = TNB_STAGE * MB / 4 / 512, VB = (TNB_STAGE * N / 4 + 511) / 512;   // float4 per thread per stage
-  static_assert(NT % MA == 0 && NH % NBATCH == 0 && VA >= 1, "shape");
+  static_assert(NT % MA == 0 && NH % NBATCH == 0 && VA >= 1 && (!PURE || (BF_B && !PERIODIC)), "shape");
+  constexpr int PB = PURE ? 1 : 3;                   // planes of B in LDS
   __shared__ __attribute__((aligned(16))) unsigned char la[2][3][TNB_STAGE * ROWA];
-  __shared__ __attribute__((aligned(16))) unsigned char lb[2][3][TNB_STAGE * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char lb[2][PB][TNB_STAGE * ROWB];
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
       if (BF_B) {
         // (raw bits; unpacked when the stage is published -- converting here would wait for the load at once)
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok && from0) v = ld4(B0 + e1 + 4 * c4);
+        if (!PURE && ok && from0) v = ld4(B0 + e1 + 4 * c4);
         if (ok && !from0) {
           const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(B1) + e1 + 4 * c4);
           v = f32x4{bitsf(raw.x), bitsf(raw.y), 0.f, 0.f};
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
       const int idx = tid + 512 * j, row = idx / (N / 4), c4 = idx % (N / 4);
       if (idx < TNB_STAGE * N / 4) {
         const unsigned off = (unsigned)(row * ROWB + c4 * 8);
-        if (BF_B && row_is_bf16(st * TNB_STAGE + row)) {
+        if (PURE) {
+          *reinterpret_cast<uint2*>(&lb[buf][0][0] + off) = uint2{fbits(vb[j][0]), fbits(vb[j][1])};
+        } else if (BF_B && row_is_bf16(st * TNB_STAGE + row)) {
           unsigned char* p0 = &lb[buf][0][0] + off;
           *reinterpret_cast<uint2*>(p0) = uint2{fbits(vb[j][0]), fbits(vb[j][1])};
           *reinterpret_cast<uint2*>(p0 + TNB_STAGE * ROWB) = uint2{0u, 0u};
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
     // one stage: products from buffer buf, then the planes of stage st + 1 (waiting in Snext) into buffer buf ^ 1,
     // then -- behind the barrier, i.e. behind every MFMA of the stage -- the request for stage st + 3 into Snext
     auto stage = [&](size_t st, int buf, Stage& Snext) __attribute__((always_inline)) {
-      const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * 3 * TNB_STAGE * ROWB;
+      const unsigned oa = (unsigned)buf * 3 * TNB_STAGE * ROWA, ob = (unsigned)buf * PB * TNB_STAGE * ROWB;
       SPLIT_STAMP(0)
       Frag3 Af[MA];
 #pragma unroll
@@ -355,13 +360,21 @@ __global__ __launch_bounds__(512) void tn_gemm_big(size_t R, int stages_per_wg, 
 #pragma unroll
         for (int c = 0; c < NBATCH; ++c)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) Bf[c].p[p] = tr_frag(trB + ob + p * (TNB_STAGE * ROWB) + (c0 + c) * 32, ROWB);
+          for (int p = 0; p < PB; ++p) Bf[c].p[p] = tr_frag(trB + ob + p * (TNB_STAGE * ROWB) + (c0 + c) * 32, ROWB);
         __builtin_amdgcn_sched_barrier(0);        // every fragment read of the batch is issued before its first MFMA
         SPLIT_STAMP(1)                            // (diagnostic build: + the wait for the fragments)
 #pragma unroll
         for (int c = 0; c < NBATCH; ++c)
 #pragma unroll
-          for (int a = 0; a < MA; ++a) acc[a][c0 + c] = mfma6(Af[a], Bf[c], acc[a][c0 + c]);
+          for (int a = 0; a < MA; ++a) {
+            if (PURE) {
+              f32x4 v = mfma_bf16(Af[a].p[2], Bf[c].p[0], acc[a][c0 + c]);
+              v = mfma_bf16(Af[a].p[1], Bf[c].p[0], v);
+              acc[a][c0 + c] = mfma_bf16(Af[a].p[0], Bf[c].p[0], v);
+            } else {
+              acc[a][c0 + c] = mfma6(Af[a], Bf[c], acc[a][c0 + c]);
+            }
+          }
         __builtin_amdgcn_sched_barrier(0);
         float touch = 0.f;                         // all of the batch's MFMAs have retired before Bf / Af are reloaded
 #pragma unroll
@@ -694,26 +707,54 @@ bool tn_gemm_big_supported(int M, int N) { return (M == 128 || M == 256) && (N =
 size_t tn_gemm_big_ws(size_t R, int M, int N) {
   int spw;
   const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
-  return align256((size_t)nch * nblk * 128 * N * sizeof(float));
+  // (twice the chunks of the product: with bf16 rows of B the rows that pair with fp32 h0 are a product of their own,
+  // its partials behind the others')
+  return align256((size_t)2 * nch * nblk * 128 * N * sizeof(float));
 }
 
 int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float* B0, const void* B1v, size_t shiftB,
                     int ldb, float* part, float* C, int ldc, hipStream_t s, bool bf_b) {
   if (!tn_gemm_big_supported(M, N)) return FASTGRNN_ERR_UNSUPPORTED;
   int spw;
-  const int nblk = M / 128, nch = tnb_chunks(R, nblk, &spw);
+  const int nblk = M / 128;
+  int nch = tnb_chunks(R, nblk, &spw);
   dim3 grid(((nch + 7) / 8) * 8 * nblk);
   const float* B1 = (const float*)B1v;
+  // bf16 rows of B: with shiftB = 0 every row is bf16 (the PURE variant: three MFMA terms); otherwise the first
+  // shiftB rows pair with fp32 rows of B0 (h0) -- a product of its own over those rows, its partials behind the
+  // others' in the workspace, one reduction over both
+  int nch0 = 0;                                      // chunks of the fp32 head product
+  if (bf_b && shiftB > 0 && shiftB < R) {
+    const size_t R0 = shiftB, Rb = R - shiftB;
+    // the bf16 body: rows shiftB .. R-1 of A against rows 0 .. of B1
+    nch = tnb_chunks(Rb, nblk, &spw);
+    grid = dim3(((nch + 7) / 8) * 8 * nblk);
+    int spw0;
+    nch0 = tnb_chunks(R0, nblk, &spw0);
+    float* part0 = part + (size_t)nch * nblk * 128 * N;      // (behind the body's partials: one reduction over both)
+    dim3 grid0(((nch0 + 7) / 8) * 8 * nblk);
+#define TNB_HEAD(n) \
+    if (N == n) hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid0, dim3(512), 0, s, R0, spw0, nblk, nch0, A, lda, B0, B0, R0, ldb, part0);
+    TNB_HEAD(32) TNB_HEAD(64) TNB_HEAD(128) TNB_HEAD(256)
+#undef TNB_HEAD
+    A += R0 * (size_t)lda;
+    R = Rb;
+    shiftB = 0;
+  }
+  const bool pure = bf_b && shiftB == 0;
 #define TNB_CASE(n)                                                                                                               \
   if (N == n) {                                                                                                                   \
-    if (bf_b) hipLaunchKernelGGL((tn_gemm_big<n / 16, false, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part); \
+    if (pure) hipLaunchKernelGGL((tn_gemm_big<n / 16, false, true, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part); \
+    else if (bf_b) hipLaunchKernelGGL((tn_gemm_big<n / 16, false, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part); \
     else hipLaunchKernelGGL((tn_gemm_big<n / 16>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);   \
   }
   TNB_CASE(32) TNB_CASE(64) TNB_CASE(128)
 #undef TNB_CASE
   if (N == 256) {
     // (a stage of tn_gemm_w4 takes its rows of B from ONE source, fp32)
-    if (bf_b)
+    if (pure)
+      hipLaunchKernelGGL((tn_gemm_big<16, false, true, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
+    else if (bf_b)
       hipLaunchKernelGGL((tn_gemm_big<16, false, true>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
     else if (shiftB == 0 || shiftB >= R || shiftB % TNB_STAGE == 0)
       hipLaunchKernelGGL((tn_gemm_w4<16, TNW4_PRE>), grid, dim3(256), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
@@ -721,7 +762,7 @@ int tn_gemm_big_run(size_t R, int M, int N, const float* A, int lda, const float
       hipLaunchKernelGGL((tn_gemm_big<16>), grid, dim3(512), 0, s, R, spw, nblk, nch, A, lda, B0, B1, shiftB, ldb, part);
   }
   const int total = M * N;
-  hipLaunchKernelGGL(tn_big_reduce, dim3((total + 63) / 64), dim3(1024), 0, s, nch, nblk, N, (const float*)part, C, ldc);
+  hipLaunchKernelGGL(tn_big_reduce, dim3((total + 63) / 64), dim3(1024), 0, s, nch + nch0, nblk, N, (const float*)part, C, ldc);
   return hipGetLastError() == hipSuccess ? FASTGRNN_OK : FASTGRNN_ERR_LAUNCH;
 }
 
