@@ -38,7 +38,8 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
   constexpr int VPT = RG_ROWS * K / 4 / 512;      // float4 per thread per stage
   constexpr int KB = KS < 4 ? KS : 4;             // K-steps per fragment batch
   static_assert(NT % WN == 0 && VPT >= 1 && KS % KB == 0, "shape");
-  __shared__ __attribute__((aligned(16))) unsigned char pl[2][3][RG_ROWS * ROWB];
+  constexpr int PA = BF_IN ? 1 : 3;               // planes of A in LDS: a bf16 value is its own first plane, the others zero
+  __shared__ __attribute__((aligned(16))) unsigned char pl[2][PA][RG_ROWS * ROWB];
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,15 +95,16 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       const int idx = tid + 512 * j, row = idx / (K / 4), c4 = idx % (K / 4);
-      f32x4 v;
-      if (BF_IN) v = f32x4{bitsf(vraw[j].x << 16), bitsf(vraw[j].x & 0xFFFF0000u), bitsf(vraw[j].y << 16), bitsf(vraw[j].y & 0xFFFF0000u)};
-      else v = va[j];
-      uint2 q0, q1, q2;
-      split_quad(v, q0, q1, q2);
       const unsigned off = (unsigned)(row * ROWB + c4 * 8);
-      *reinterpret_cast<uint2*>(&pl[buf][0][off]) = q0;
-      *reinterpret_cast<uint2*>(&pl[buf][1][off]) = q1;
-      *reinterpret_cast<uint2*>(&pl[buf][2][off]) = q2;
+      if (BF_IN) {                                  // the raw 8 bytes ARE plane 0 (no vector arithmetic at all)
+        *reinterpret_cast<uint2*>(&pl[buf][0][off]) = vraw[j];
+      } else {
+        uint2 q0, q1, q2;
+        split_quad(va[j], q0, q1, q2);
+        *reinterpret_cast<uint2*>(&pl[buf][0][off]) = q0;
+        *reinterpret_cast<uint2*>(&pl[buf][PA > 1 ? 1 : 0][off]) = q1;
+        *reinterpret_cast<uint2*>(&pl[buf][PA > 2 ? 2 : 0][off]) = q2;
+      }
     }
   };
 
@@ -130,13 +132,21 @@ __global__ __launch_bounds__(512) void rows_gemm_split(size_t R, int stages_per_
 #pragma unroll
         for (int s = 0; s < KB; ++s)
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < PA; ++p)
             Bf[s].p[p] = *reinterpret_cast<const u32x4*>(&pl[buf][p][(rt * 16 + i) * ROWB + (32 * (k0 + s) + 8 * g) * 2]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KB; ++s)
 #pragma unroll
-          for (int a = 0; a < NPW; ++a) mfma6_hl(Wf[a][k0 + s], Bf[s], hi[a], lo[a]);
+          for (int a = 0; a < NPW; ++a) {
+            if (BF_IN) {                            // three of mfma6_hl's six terms, in its order (the others multiply zeros)
+              lo[a] = mfma_bf16(Wf[a][k0 + s].p[2], Bf[s].p[0], lo[a]);
+              lo[a] = mfma_bf16(Wf[a][k0 + s].p[1], Bf[s].p[0], lo[a]);
+              hi[a] = mfma_bf16(Wf[a][k0 + s].p[0], Bf[s].p[0], hi[a]);
+            } else {
+              mfma6_hl(Wf[a][k0 + s], Bf[s], hi[a], lo[a]);
+            }
+          }
         __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks MFMAs below the read)
         float touch = 0.f;                         // every accumulator of the batch has retired before Bf is reloaded
 #pragma unroll
