@@ -486,6 +486,10 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
     const float* p0 = aux0 + step;
     const float* p1 = PREACT ? aux0 : aux1 + step;
     const float* ht = (t == 0) ? h0 : hs + (sstep - (BF ? (size_t)hsT / 2 : (size_t)hsT));   // .cu:478-481
+    // (bf16: step 0 reads the fp32 h0, the others a bf16 row of hs.  BOTH loads are issued every step -- the bf16 one
+    // from row 0 of hs at step 0, the fp32 one from h0, an L2 hit -- and the value is picked with selects: no
+    // wave-uniform branch around memory instructions inside the scan)
+    const float* hb = (t == 0) ? hs : ht;
     const unsigned lane_g = g_last ? lane_c0 : lane_c, lane_h = (t == 0) ? lane_c0 : lane_c;
     const bool g_zero = (g_last && t != Tn - 1) || (RAGGED && !valid);
 #pragma unroll
@@ -495,7 +499,13 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       e.g[mt] = g_zero ? z4 : (BF ? ldgb(gt, lane_g + 64u * mt) : ldg(gt, lane_g + 64u * mt));
       e.a0[mt] = ldg(p0, lane_c + 64u * mt);
       if (!PREACT) e.a1[mt] = ldg(p1, lane_c + 64u * mt);
-      e.h[mt] = (BF && t > 0) ? ldgb(ht, lane_h + 64u * mt) : ldg(ht, lane_h + 64u * mt);   // (h0 is fp32)
+      if (BF) {
+        const f32x4 h32 = ldg(h0, lane_c0 + 64u * mt), h16 = ldgb(hb, lane_c + 64u * mt);
+        const bool first = t == 0;
+        e.h[mt] = f32x4{first ? h32[0] : h16[0], first ? h32[1] : h16[1], first ? h32[2] : 0.f, first ? h32[3] : 0.f};
+      } else {
+        e.h[mt] = ldg(ht, lane_h + 64u * mt);
+      }
     }
   };
 
@@ -519,7 +529,9 @@ __global__ __launch_bounds__(512) void bwd_scan_h256(
       }
       if (BF) {
         e.g[mt] = widen(e.g[mt]);
-        if (t > 0) e.h[mt] = widen(e.h[mt]);
+        const f32x4 hw = widen(e.h[mt]);               // (selects, no branch: see load_ew)
+        const bool first = t == 0;
+        e.h[mt] = f32x4{first ? e.h[mt][0] : hw[0], first ? e.h[mt][1] : hw[1], first ? e.h[mt][2] : hw[2], first ? e.h[mt][3] : hw[3]};
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -753,7 +753,12 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
   // dW += d_pre_s^T x_s, dU += d_pre_s^T h_{s-1} (.cu:539-540) for the step pair (sU, sU-1): this wave's
   // 2 row tiles x 5 column tiles, 6 terms each.  Fragments come out of the plane images through the
   // hardware transpose read.
-  auto weight_grads = [&](int sU) __attribute__((always_inline)) {
+  // PURE3 (compile time): bf16 sequences and a pair beyond step 0 -- x and h_prev are their own first planes, the other two
+  // are zero: three of mfma6's six terms, in its order (the same bits).  The pair (1, 0) reads the fp32 h0 and keeps six.
+  // (Decided per call site, not by a branch on sU: a wave-uniform branch between the MFMAs of a scan step brought back
+  // intermittent wrong d_x rows -- 2 of 12 test processes -- that the static scans do not see: DESIGN.md 4.0.)
+  auto weight_grads = [&](auto pure_tag, int sU) __attribute__((always_inline)) {
+    constexpr bool PURE3 = decltype(pure_tag)::value;
     const unsigned im = lds_img + (unsigned)(((g < 2) ? sU : sU - 1) & 3) * IMG;
     const unsigned trA = im + trA_off, trH = im + trH_off, trX = im + trX_off;
     Frag3 Af[2];
@@ -780,10 +785,21 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
 #pragma unroll
       for (int c = 0; c < NB; ++c) load_b(C0 + c, Bf[c]);
       fragments_landed();
+      if constexpr (PURE3) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c)
+        for (int c = 0; c < NB; ++c)
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2) acc[a2][C0 + c] = mfma6(Af[a2], Bf[c], acc[a2][C0 + c]);
+          for (int a2 = 0; a2 < 2; ++a2) {
+            f32x4 v = mfma_bf16(Af[a2].p[2], Bf[c].p[0], acc[a2][C0 + c]);
+            v = mfma_bf16(Af[a2].p[1], Bf[c].p[0], v);
+            acc[a2][C0 + c] = mfma_bf16(Af[a2].p[0], Bf[c].p[0], v);
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2) acc[a2][C0 + c] = mfma6(Af[a2], Bf[c], acc[a2][C0 + c]);
+      }
       __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks MFMAs below the read)
       float touch = 0.f;                       // one element of every accumulator of the batch: all have retired
 #pragma unroll
@@ -870,7 +886,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
     __builtin_amdgcn_sched_barrier(0);
     SPLIT_STAMP(2)
     // this wave's share of a step pair's dW / dU: 60 independent MFMAs and no VALU work
-    if (heavy) weight_grads(EVEN ? t + 1 : t + 2);
+    if (heavy) weight_grads(std::bool_constant<BF && !LAST>{}, EVEN ? t + 1 : t + 2);
     SPLIT_STAMP(3)
     lds_barrier();
     SPLIT_STAMP(4)
@@ -898,7 +914,7 @@ __global__ __launch_bounds__(512) void bwd_scan_split_w8(
 #ifdef FASTGRNN_DIAG_STAMPS
   if (blockIdx.x == 7 && l == 0) { for (int k2 = 0; k2 < 8; ++k2) g_sdiag[wv][k2] = dsum[k2]; }
 #endif
-  if constexpr (ch == 1) weight_grads(1);           // pair (1, 0), column tiles NC..2NC-1
+  if constexpr (ch == 1) weight_grads(std::false_type{}, 1);   // pair (1, 0), column tiles NC..2NC-1
   finish_dx(0);
   // ---- flush ---------------------------------------------------------------------------------
   if (valid) st4(d_h0 + (size_t)b * H + n0, dh);

@@ -16,6 +16,10 @@ if os.environ.get("DET_ONLY_DENSE"):                     # bisecting the headlin
     SHAPES = SHAPES[:2]
 elif os.environ.get("FASTGRNN_HIP_LIB") is None:        # round-2 shapes (not in an older library given for comparison)
     SHAPES += ((128, 0, 4096, 256), (256, 0, 4096, 32), (256, 0, 50, 32))
+BF16 = bool(os.environ.get("DET_BF16"))                 # bf16 sequences (x, hs, grad_hs, d_x): one-saved-tensor contract only
+if BF16:
+    SHAPES = ((128, 0, 4096, 32), (128, 0, 40, 32), (128, 0, 40, 256), (128, 0, 4096, 256), (256, 0, 40, 32), (256, 0, 4096, 32),
+              (256, 0, 40, 64))
 for (H, r, B, F) in SHAPES:
     torch.manual_seed(1)
     if r:
@@ -28,7 +32,9 @@ for (H, r, B, F) in SHAPES:
     bz = torch.randn(1, H, device=dev); bh = torch.randn(1, H, device=dev)
     zeta = torch.ones(1, 1, device=dev); nu = -4 * torch.ones(1, 1, device=dev)
     x = torch.randn(T, B, F, device=dev); h0 = 0.3 * torch.randn(B, H, device=dev); G = torch.randn(T, B, H, device=dev)
-    for preact in (4, 0):
+    if BF16:
+        x, G = x.to(torch.bfloat16), G.to(torch.bfloat16)
+    for preact in ((4,) if BF16 else (4, 0)):
         fl = preact | extra
         first = None
         nbad = 0

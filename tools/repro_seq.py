@@ -42,10 +42,18 @@ def run(d, fl):
     return [o for o in list(outs) + list(g) if o.numel()]
 
 
+BF16 = bool(os.environ.get("REPRO_BF16"))              # bf16 sequences (one-saved-tensor contract; dense shapes)
+if BF16:
+    SHAPES = [(25, 40, 256, 128, 1), (25, 40, 32, 128, 1), (25, 40, 32, 256, 1), (25, 40, 64, 256, 1), (99, 64, 256, 128, 1),
+              (23, 37, 256, 128, 1), (12, 16, 128, 128, 1), (7, 33, 64, 128, 1), (31, 48, 256, 128, 1), (31, 37, 64, 256, 1),
+              (9, 33, 32, 256, 1), (31, 64, 32, 128, 1), (8, 17, 64, 128, 1), (7, 50, 256, 128, 1)]
 if os.environ.get("REPRO_SHORT"):
     SHAPES = SHAPES[:15]
 POISON = [int(v, 0) for v in os.environ.get("REPRO_POISON", "").split(",") if v]
 data = [make(sh[0], sh[1], sh[2], sh[3], 10 + k, sh[5] if len(sh) > 5 else 0) for k, sh in enumerate(SHAPES)]
+if BF16:
+    for d_ in data:
+        d_["x"], d_["G"] = d_["x"].to(torch.bfloat16), d_["G"].to(torch.bfloat16)
 first = {}
 nbad = 0
 per_shape = {}
