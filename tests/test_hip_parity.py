@@ -1061,13 +1061,16 @@ def test_model_tail_last_state_plus_head_matches_the_reference_chain():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F,H,r", [(32, 128, None), (32, 256, None), (64, 256, None), (256, 128, None), (32, 256, 16), (32, 256, 32)])
 @pytest.mark.parametrize("batch_first", [False, True])
-def test_module_forward_without_grad_saves_nothing_and_matches_the_training_forward(batch_first):
+def test_module_forward_without_grad_saves_nothing_and_matches_the_training_forward(batch_first, F, H, r):
     """Under torch.no_grad() the module runs the hs-only forward (no pre-activation written); same bits as the
-    training forward, also after a call under inference_mode (the cached default state must not be an inference tensor)."""
+    training forward, also after a call under inference_mode (the cached default state must not be an inference tensor).
+    Every kernel family: dense H=128 (fused and wide input), dense H=256 (F=32 and the frame-GEMM form), low-rank,
+    multiplied-out factors."""
     torch.manual_seed(3)
-    T, B, F, H = 17, 40, 32, 128
-    m = FastGRNNCUDA(F, H, batch_first=batch_first, device=DEV)
+    T, B = 17, 40
+    m = FastGRNNCUDA(F, H, wRank=r, uRank=r, batch_first=batch_first, device=DEV)
     x = torch.randn((B, T, F) if batch_first else (T, B, F), device=DEV)
     with torch.inference_mode():
         hs_i = m(x).clone()
@@ -1076,6 +1079,13 @@ def test_module_forward_without_grad_saves_nothing_and_matches_the_training_forw
     xg = x.clone().requires_grad_(True)
     hs_t = m(xg)
     assert hs_t.requires_grad and not hs_n.requires_grad
-    assert torch.equal(hs_n, hs_t.detach()) and torch.equal(hs_i, hs_n)
+    assert torch.equal(hs_i, hs_n)
+    if r == 16:
+        # the register-resident low-rank forward's hs-only and pre-activation-saving instantiations are compiled
+        # separately and do not round their gate arithmetic identically (multiply-add contraction around the value
+        # that one of them stores and the other does not): the same value to fp32 rounding, not the same bits
+        assert float((hs_n - hs_t.detach()).abs().max()) <= 2e-6 * max(1.0, float(hs_t.detach().abs().max()))
+    else:
+        assert torch.equal(hs_n, hs_t.detach())
     hs_t.square().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
