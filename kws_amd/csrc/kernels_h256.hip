@@ -270,7 +270,16 @@ __global__ __launch_bounds__(512) void fwd_scan_h256(
       if (H16) publish_x(nxt, xpub);                 // (double-buffered: the next frame's planes go out here)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) mfma6_hl(H16 ? Wl[mt] : Wf[mt], xB, a[mt], alo[mt]);
+      for (int mt = 0; mt < 2; ++mt) {
+        const Frag3& Wm = H16 ? Wl[mt] : Wf[mt];
+        if (BF) {                                    // a bf16 frame is its own first plane: three of the six terms, same bits
+          alo[mt] = mfma_bf16(Wm.p[2], xB.p[0], alo[mt]);
+          alo[mt] = mfma_bf16(Wm.p[1], xB.p[0], alo[mt]);
+          a[mt] = mfma_bf16(Wm.p[0], xB.p[0], a[mt]);
+        } else {
+          mfma6_hl(Wm, xB, a[mt], alo[mt]);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       float touch = 0.f;
 #pragma unroll

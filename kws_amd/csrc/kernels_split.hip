@@ -416,7 +416,15 @@ __global__ __launch_bounds__(512) void fwd_scan_split_w8(
     SPLIT_STAMP(1)
     // big and small terms in accumulators of their own (see mfma6_hl), summed once at the end
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, alo = a;
-    if (PREIN) a = pcur; else mfma6_hl(Wf, xB, a, alo);
+    if (PREIN) {
+      a = pcur;
+    } else if (BF) {                                 // a bf16 frame is its own first plane: three of the six terms, same bits
+      alo = mfma_bf16(Wf.p[2], xB.p[0], alo);
+      alo = mfma_bf16(Wf.p[1], xB.p[0], alo);
+      a = mfma_bf16(Wf.p[0], xB.p[0], a);
+    } else {
+      mfma6_hl(Wf, xB, a, alo);
+    }
     if (H16) {
       f32x4 ah = f32x4{0.f, 0.f, 0.f, 0.f}, ahlo = ah;
 #pragma unroll
