@@ -6,12 +6,15 @@
 //                     the recurrence (.cu:356,368 evaluates it per step) and  d_x = d_pre . W  behind it (.cu:538)
 //   tn_gemm_big       C[M,N] = A[R,M]^T . B[R,N]       the weight gradients  dW = d_pre^T X,  dU = d_pre^T H_prev
 //                     (.cu:539-540 accumulates them per step) for M, N up to 256
+//   tn_gemm_w4        the same product for N = 256 as one wave per SIMD with the operand split between its own MFMAs
 //
 // Same arithmetic as the scans: every fp32 operand is split exactly into three bf16 planes, six MFMA terms per
 // product on v_mfma_f32_16x16x32_bf16, fp32 accumulation, big and small terms in separate accumulators; results
-// are fp32 tensors with fp32-level accuracy.  Both kernels are written to the operand rule of DESIGN.md 4.0
-// (fragment reads before the first MFMA of a batch, completion reads before registers are reused) and are
-// checked by tools/war_scan.py.
+// are fp32 tensors with fp32-level accuracy.  An operand that ARRIVES as bf16 (FASTGRNN_BF16_IO sequences) is its own
+// first plane, the other two are zero: it is published from its raw bytes and multiplied with three terms
+// (rows_gemm_split<.., BF_IN>, tn_gemm_big<.., BF_B, PURE>).  All kernels are written to the operand rule of
+// DESIGN.md 4.0 (fragment reads before the first MFMA of a batch, completion reads before registers are reused) and
+// are checked by tools/war_scan.py and tools/lds_branch_vmem_scan.py.
 #include "split_common.h"
 
 namespace fastgrnn {
